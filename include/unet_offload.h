@@ -1,0 +1,229 @@
+/*
+ * unet_offload.h -- C ABI of the MI355X (gfx950) offload for the receive/transmit
+ * integrity path of the ikanago/unet userspace network stack: RFC 1071 Internet
+ * checksum, IPv4 / UDP / ICMP / Ethernet header parse + validate, and the
+ * accept/drop verdict each frame would get from the stack's own recv functions.
+ *
+ * Everything here is plain C: pointers, sizes, fixed-width integers.  All compute
+ * runs in hand-written HIP kernels; there is no CPU compute path behind these
+ * entry points (the only host-side arithmetic is the synthetic-trace generator's
+ * host twin and the arena packer, neither of which produces checksums or verdicts
+ * for a caller).  Every function returns 0 on success or a negative UNET_E_* code;
+ * unet_last_error() returns a thread-local description of the last failure.
+ *
+ * "Reference" citations are file:line in ikanago/unet @ 2024_10_08.
+ */
+#ifndef UNET_OFFLOAD_H
+#define UNET_OFFLOAD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ errors */
+#define UNET_OK 0
+#define UNET_E_INVAL (-1)   /* bad argument (null pointer, n out of range, misaligned arena ...) */
+#define UNET_E_NODEV (-2)   /* no usable HIP device / device id out of range */
+#define UNET_E_HIP (-3)     /* a HIP runtime call failed; see unet_last_error() */
+#define UNET_E_NOMEM (-4)   /* host or device allocation failed */
+#define UNET_E_RANGE (-5)   /* a frame length > 65535 or an offset outside the arena */
+
+/* ---------------------------------------------------------------- verdicts */
+/* One code per outcome of the reference's receive path; the FIRST failing check
+ * in the reference's evaluation order wins.  Codes tagged "panic" are inputs on
+ * which the reference indexes out of bounds; the offload defines a drop for them. */
+enum unet_verdict {
+    UNET_V_NONE = 0,                 /* slot not written */
+    UNET_V_DROP_L2_TRUNCATED = 1,    /* frame < 14 B: panic, src/devices/ethernet.rs:50-52 */
+    UNET_V_DROP_L2_ETHERTYPE = 2,    /* ethertype not 0x0800/0x0806, src/protocols.rs:33-42 */
+    UNET_V_DROP_L2_NOT_FOR_ME = 3,   /* dst MAC neither ours nor ff:ff:ff:ff:ff:ff, src/devices/ethernet.rs:63-71 */
+    UNET_V_PASS_ARP = 4,             /* ethertype 0x0806: goes to the ARP queue on the host, src/protocols.rs:93 */
+    UNET_V_DROP_L3_TRUNCATED = 5,    /* packet < 20 B or IHL*4 > len: panic, src/protocols/ipv4.rs:189-203,415 */
+    UNET_V_DROP_L3_PROTO = 6,        /* protocol byte not ICMP/UDP; checked before anything else, src/transport.rs:18-26 via ipv4.rs:189 */
+    UNET_V_DROP_L3_VERSION = 7,      /* src/protocols/ipv4.rs:129-133 */
+    UNET_V_DROP_L3_IHL_SHORT = 8,    /* IHL*4 < 20, src/protocols/ipv4.rs:134-138 */
+    UNET_V_DROP_L3_IHL_LONG = 9,     /* IHL*4 >= 60 (IHL 15 is rejected), src/protocols/ipv4.rs:139-143 */
+    UNET_V_DROP_L3_FRAGMENT = 10,    /* MF set or fragment offset != 0, src/protocols/ipv4.rs:145-147 */
+    UNET_V_DROP_L3_CSUM = 11,        /* checksum over the first 20 header bytes != 0, src/protocols/ipv4.rs:152-157 */
+    UNET_V_IGNORE_L3_NOT_FOR_ME = 12,/* dst not unicast/broadcast/255.255.255.255: Ok(()) silently, src/protocols/ipv4.rs:402-407 */
+    UNET_V_DROP_ICMP_TRUNCATED = 13, /* ICMP message < 8 B: panic, src/transport/icmp.rs:52-55 */
+    UNET_V_DROP_ICMP_TYPE = 14,      /* type not 0/8, src/transport/icmp.rs:16-22 */
+    UNET_V_ACCEPT_ICMP_ECHO = 15,    /* echo request; host sends the reply, src/transport/icmp.rs:110-120 */
+    UNET_V_ACCEPT_ICMP_ECHOREPLY = 16,/* src/transport/icmp.rs:103-121 */
+    UNET_V_DROP_UDP_SHORT = 17,      /* segment < 8 B, src/transport/udp.rs:226-228 */
+    UNET_V_DROP_UDP_LEN = 18,        /* buffer length != UDP length field, src/transport/udp.rs:232-238 */
+    UNET_V_DROP_UDP_CSUM = 19,       /* pseudo-header checksum != 0, src/transport/udp.rs:247-254 */
+    UNET_V_ACCEPT_UDP = 20,          /* continues to PCB lookup on the host, src/transport/udp.rs:256-277 */
+    /* Extension (no counterpart in the reference, only with unet_iface.ext_tcp = 1): */
+    UNET_V_DROP_TCP_SHORT = 21,      /* segment < 20 B */
+    UNET_V_DROP_TCP_DOFF = 22,       /* data offset < 5 or data offset*4 > segment length */
+    UNET_V_DROP_TCP_CSUM = 23,       /* pseudo-header (protocol 6) checksum != 0 */
+    UNET_V_ACCEPT_TCP = 24,
+    /* Only produced by unet_ipv4_validate*: header parsed and validate() returned Ok. */
+    UNET_V_L3_HEADER_OK = 25,
+    UNET_V_COUNT = 32                /* size of a counter array indexed by verdict */
+};
+
+/* Per-frame result, 4 bytes.
+ *  verdict: enum unet_verdict.
+ *  proto:   IPv4 protocol byte (packet[9]) whenever the IPv4 header was reachable
+ *           (>= 20 bytes of L3), else 0.
+ *  csum:    the checksum value the reference computes and tests/prints on this path:
+ *           DROP_L3_CSUM          -> calculate_checksum(header[0..20], 0)  (nonzero)
+ *           DROP_UDP_CSUM / ACCEPT_UDP -> calculate_checksum(pseudo, !calculate_checksum(segment, 0))
+ *           DROP_TCP_CSUM / ACCEPT_TCP -> same with protocol 6 (extension)
+ *           ACCEPT_ICMP_ECHO      -> checksum of the echo reply the reference sends
+ *                                    (type 0, same code/values/data; icmp.rs:75-85,110-120)
+ *           every other verdict   -> 0
+ */
+typedef struct unet_result {
+    uint16_t csum;
+    uint8_t verdict;
+    uint8_t proto;
+} unet_result;
+
+#define UNET_MODE_L3 0 /* records are L3 packets starting at the IPv4 header (what ipv4::recv gets) */
+#define UNET_MODE_L2 1 /* records are Ethernet frames starting at the destination MAC (what ethernet::recv reads) */
+
+/* Receiving interface: the constants the reference keeps in Ipv4Interface / NetDevice
+ * (src/protocols/ipv4.rs:209-229, src/devices.rs:75-90).  Addresses are the u32 value of
+ * Ipv4Address (big-endian bytes read as a number, e.g. 192.0.2.2 = 0xC0000202). */
+typedef struct unet_iface {
+    uint32_t unicast;
+    uint32_t broadcast; /* unicast & 0xffffff00 | ~netmask & 0xff, src/protocols/ipv4.rs:220 */
+    uint8_t mac[6];     /* used in UNET_MODE_L2 only */
+    uint8_t mode;       /* UNET_MODE_L3 or UNET_MODE_L2 */
+    uint8_t ext_tcp;    /* 0: protocol 6 -> DROP_L3_PROTO exactly like the reference; 1: TCP extension */
+} unet_iface;
+
+typedef struct unet_ctx unet_ctx;
+
+/* ------------------------------------------------------------ context */
+/* Bind a context to one HIP device.  Creates two streams and pinned staging used by the
+ * host-pointer entry points.  One context per thread/GPU (thread-compatible, not thread-safe). */
+int unet_open(int device_id, unet_ctx** out_ctx);
+void unet_close(unet_ctx* ctx);
+const char* unet_last_error(void);
+int unet_device_count(void);
+/* Block until all work queued on the context's own streams is done. */
+int unet_sync(unet_ctx* ctx);
+
+/* -------------------------------------------------- frame arena layout */
+/* A batch is `n` records in one byte arena.  Record i starts at byte 16*off16[i]
+ * (every record starts on a 16-byte boundary) and is len[i] bytes long (0..65535).
+ * If off16 is NULL the records sit at a fixed stride: record i starts at i*16*stride16.
+ * The arena must be readable up to the next multiple of 16 past every record's end
+ * (the packer pads); pad bytes are never interpreted. */
+
+/* ------------------------------------------- a1: calculate_checksum */
+/* Batched `utils::calculate_checksum(data, sum)` (src/utils.rs:1-17): out[i] =
+ * checksum of record i seeded with seeds[i] (seeds may be NULL = all 0).
+ * *_dev: every pointer is device memory of ctx's device; the kernel is enqueued on
+ * `stream` (a hipStream_t; NULL = the context's compute stream) and the call returns
+ * without waiting. */
+int unet_csum_batch_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_t arena_bytes,
+                        const uint32_t* d_off16, uint32_t stride16, const uint32_t* d_len,
+                        const uint16_t* d_seeds, uint32_t n, uint16_t* d_out);
+/* Host-pointer form: stages through pinned memory, runs the same kernel, waits. */
+int unet_csum_batch(unet_ctx* ctx, const uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16,
+                    uint32_t stride16, const uint32_t* len, const uint16_t* seeds, uint32_t n,
+                    uint16_t* out);
+/* Exact shape of the reference leaf `calculate_checksum(data: &[u8], sum: u16) -> u16`
+ * (src/utils.rs:1; call sites ipv4.rs:154,387 icmp.rs:83 udp.rs:200,202,229,247) for one
+ * buffer of at most 65535 bytes.  Runs on the GPU like everything else; it exists so a
+ * host shim can keep the reference signature, not because one buffer at a time is fast. */
+int unet_csum(unet_ctx* ctx, const uint8_t* data, size_t len, uint16_t seed, uint16_t* out);
+
+/* --------------------------- a2-a4: Ipv4Header::try_from + validate */
+/* `n` bare 20-byte IPv4 headers packed back to back (stride 20 bytes, d_hdrs 16-byte
+ * aligned).  out[i] = verdict of Ipv4Header::try_from (src/protocols/ipv4.rs:185-207) followed
+ * by validate() (ipv4.rs:128-157): one of DROP_L3_PROTO / VERSION / IHL_SHORT / IHL_LONG /
+ * FRAGMENT / CSUM or L3_HEADER_OK.  Only iface->ext_tcp is read. */
+int unet_ipv4_validate_dev(unet_ctx* ctx, void* stream, const uint8_t* d_hdrs, uint32_t n,
+                           const unet_iface* iface, unet_result* d_out);
+int unet_ipv4_validate(unet_ctx* ctx, const uint8_t* hdrs, uint32_t n, const unet_iface* iface,
+                       unet_result* out);
+
+/* ------------- a2-a6, a8, a11: ethernet::recv -> ipv4::recv -> udp/icmp::recv */
+/* Verdict of the reference receive path for every record: ethernet::recv
+ * (src/devices/ethernet.rs:58-75, MODE_L2 only) -> ipv4::recv (src/protocols/ipv4.rs:394-422)
+ * -> udp::recv validation (src/transport/udp.rs:219-254) or icmp::recv
+ * (src/transport/icmp.rs:97-122). */
+int unet_verify_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_t arena_bytes,
+                    const uint32_t* d_off16, uint32_t stride16, const uint32_t* d_len, uint32_t n,
+                    const unet_iface* iface, unet_result* d_out);
+int unet_verify(unet_ctx* ctx, const uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16,
+                uint32_t stride16, const uint32_t* len, uint32_t n, const unet_iface* iface,
+                unet_result* out);
+
+/* ------------------- a7, a9, a10: udp::send / icmp::send / create_ip_header */
+/* Transmit side: every record is an L3 packet (IPv4 header with IHL 5 + UDP or ICMP
+ * message) whose checksum fields hold arbitrary bytes.  Fills, in place:
+ *   packet[10..12]  = calculate_checksum(header with field zeroed, 0)        (ipv4.rs:366-391)
+ *   UDP  segment[6..8] = calculate_checksum(hdr(cksum 0)||payload, !calculate_checksum(pseudo,0))
+ *                        with NO 0x0000->0xffff substitution                (udp.rs:181-203)
+ *   ICMP message[2..4] = calculate_checksum(hdr(cksum 0)||data, 0)           (icmp.rs:75-85)
+ * The pseudo-header length is the buffer's segment length (len[i]-20), which is what
+ * udp::send uses.  Records that are not (version 4, IHL 5, protocol 1 or 17, long enough)
+ * are left untouched and reported in d_status[i] (0 = filled, else an unet_verdict drop
+ * code); d_status may be NULL. */
+int unet_generate_dev(unet_ctx* ctx, void* stream, uint8_t* d_arena, uint64_t arena_bytes,
+                      const uint32_t* d_off16, uint32_t stride16, const uint32_t* d_len, uint32_t n,
+                      uint8_t* d_status);
+int unet_generate(unet_ctx* ctx, uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16,
+                  uint32_t stride16, const uint32_t* len, uint32_t n, uint8_t* status);
+
+/* ------------------------------------------------------------ counters */
+/* Histogram of verdicts: d_counts[v] += number of results with verdict v (UNET_V_COUNT
+ * u64 slots, caller zeroes them).  The reference keeps no counters; these are what a
+ * multi-GPU job sums at the end (the only value that ever crosses GPUs). */
+int unet_count_verdicts_dev(unet_ctx* ctx, void* stream, const unet_result* d_results, uint32_t n,
+                            uint64_t* d_counts);
+
+/* --------------------------------------------------- flow-hash sharding */
+/* Build-defined 32-bit mix of the 5-tuple (ports are 0 unless protocol is UDP, or TCP
+ * with ext_tcp): the shard of a frame is hash % n_gpus, so a flow stays on one GPU.
+ * unet_flow_hash5 is the scalar definition; the _dev form parses each record's headers
+ * (MODE_L2 or MODE_L3 as in iface) and writes one hash per record (0 if the record has
+ * no complete IPv4 header). */
+uint32_t unet_flow_hash5(uint32_t src, uint32_t dst, uint8_t proto, uint16_t sport, uint16_t dport);
+int unet_flow_hash_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_t arena_bytes,
+                       const uint32_t* d_off16, uint32_t stride16, const uint32_t* d_len, uint32_t n,
+                       const unet_iface* iface, uint32_t* d_hash);
+
+/* ------------------------------------------------ synthetic frame traces */
+/* Deterministic counter-based traces used by the benchmarks and parity tests: record
+ * `idx` of trace (kind, seed) is a pure function of (kind, seed, idx), identical between
+ * the host twin and the device kernel.  All traces are UNET_MODE_L3 records addressed to
+ * `iface` with per-index fault injection. */
+#define UNET_SYNTH_IPV4_HDR20 2 /* bare 20-byte headers, stride 20 (use with unet_ipv4_validate) */
+#define UNET_SYNTH_UDP1500 3    /* 1500-byte IPv4+UDP packets, stride16 = 94 */
+#define UNET_SYNTH_IMIX 4       /* mixed 64..9000-byte TCP/UDP/ICMP packets, packed at 16-byte boundaries */
+
+/* Length of record idx (bytes) for a trace kind; pure function, host side. */
+uint32_t unet_synth_len(int kind, uint64_t seed, uint64_t idx);
+/* Fill off16[0..n) / len[0..n) for records first_idx..first_idx+n and return the arena size. */
+int unet_synth_layout(int kind, uint64_t seed, uint64_t first_idx, uint32_t n, uint32_t* off16,
+                      uint32_t* len, uint64_t* arena_bytes);
+/* Host twin: write the records into `arena` (layout as produced by unet_synth_layout). */
+int unet_synth_host(int kind, uint64_t seed, uint64_t first_idx, uint32_t n, const unet_iface* iface,
+                    const uint32_t* off16, const uint32_t* len, uint8_t* arena, uint64_t arena_bytes);
+/* Device kernel: same bytes, generated in HBM. */
+int unet_synth_dev(unet_ctx* ctx, void* stream, int kind, uint64_t seed, uint64_t first_idx, uint32_t n,
+                   const unet_iface* iface, const uint32_t* d_off16, const uint32_t* d_len,
+                   uint8_t* d_arena, uint64_t arena_bytes);
+
+/* ------------------------------------------------------- measurement aid */
+/* Read-only streaming kernel over `bytes` of device memory (16 B per lane, grid-stride):
+ * the attainable-bandwidth yardstick reported beside the 8 TB/s peak.  d_sink receives
+ * one u32 per workgroup (at least 4096 slots). */
+int unet_stream_read_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t bytes,
+                         uint32_t* d_sink);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNET_OFFLOAD_H */

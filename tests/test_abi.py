@@ -1,0 +1,119 @@
+"""CPU-only: the C-ABI library loads, exports every symbol include/unet_offload.h declares, rejects bad
+arguments without a GPU, and the host-side pieces (arena packer, trace layout, host trace twin) behave."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import unet_amd
+from unet_amd import _ffi
+from helpers import as_tuples
+from oracle import oracle_ffi as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEED = 0x756E6574
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "unet_offload.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(unet_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_ffi.LIB_PATH)
+    names = declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/unet_offload.h but not exported"
+    assert sorted(_ffi.EXPORTS) == names, "python binding and header disagree"
+
+
+def test_no_context_without_gpu_and_errors_are_reported():
+    lib = unet_amd.load_library()
+    if lib.unet_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(unet_amd.UnetError) as ei:
+        unet_amd.Offload(0)
+    assert ei.value.code == -2 and "HIP device" in str(ei.value)
+
+
+def test_missing_library_is_loud(tmp_path):
+    with pytest.raises(FileNotFoundError):
+        unet_amd.load_library(str(tmp_path / "nope.so"))
+
+
+def test_pack_arena_layout():
+    frames = [b"", b"a", b"b" * 16, b"c" * 17, b"d" * 1500]
+    arena, off16, lens = unet_amd.pack_arena(frames)
+    assert lens.tolist() == [0, 1, 16, 17, 1500]
+    assert off16.tolist() == [0, 0, 1, 2, 4]
+    assert arena.nbytes == (0 + 1 + 1 + 2 + 94) * 16
+    for f, o in zip(frames, off16):
+        assert arena[int(o) * 16:int(o) * 16 + len(f)].tobytes() == f
+
+
+def test_flow_hash_matches_oracle_definition():
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        a = [int(x) for x in rng.integers(0, 2**32, size=2)] + [int(rng.integers(0, 256))] + [int(x) for x in rng.integers(0, 65536, size=2)]
+        assert unet_amd.flow_hash5(*a) == O.flow_hash5(*a)
+
+
+@pytest.mark.parametrize("kind", [unet_amd.SYNTH_UDP1500, unet_amd.SYNTH_IMIX])
+def test_trace_layout_is_index_addressable(kind):
+    off_a, len_a, bytes_a = unet_amd.synth_layout(kind, SEED, 0, 300)
+    off_b, len_b, _ = unet_amd.synth_layout(kind, SEED, 100, 200)
+    assert (len_a[100:] == len_b).all()
+    assert [unet_amd.synth_len(kind, SEED, i) for i in range(5)] == len_a[:5].tolist()
+    slots = (len_a.astype(np.int64) + 15) // 16
+    assert (off_a[1:] == np.cumsum(slots)[:-1]).all() and bytes_a == int(slots.sum()) * 16
+    ifc = unet_amd.Iface(ext_tcp=True)
+    a, _, _ = unet_amd.synth_host(kind, SEED, 0, 300, ifc)
+    b, _, _ = unet_amd.synth_host(kind, SEED, 100, 200, ifc)
+    start = int(off_a[100]) * 16
+    assert (a[start:] == b[:len(a) - start]).all(), "record idx must not depend on the batch it is generated in"
+
+
+def test_udp1500_trace_faults_are_what_the_oracle_sees():
+    ifc = unet_amd.Iface()
+    n = 1024
+    arena, off16, lens = unet_amd.synth_host(unet_amd.SYNTH_UDP1500, SEED, 0, n, ifc)
+    assert (lens == 1500).all() and (np.diff(off16) == 94).all()
+    res = O.recv_batch(arena, off16, lens, ifc)
+    idx = np.arange(n)
+    exp = np.full(n, 20)
+    exp[idx % 64 == 7] = 19      # payload bit flip
+    exp[idx % 256 == 33] = 18    # UDP length field mismatch
+    exp[idx % 256 == 97] = 19    # transmitted checksum 0
+    assert (res["verdict"] == exp).all()
+    assert (res["csum"][exp == 20] == 0).all() and (res["csum"][exp == 19] != 0).all()
+
+
+def test_imix_trace_exercises_every_l3_l4_verdict():
+    n = 1 << 15
+    for ext in (True, False):
+        ifc = unet_amd.Iface(ext_tcp=ext)
+        arena, off16, lens = unet_amd.synth_host(unet_amd.SYNTH_IMIX, SEED, 0, n, ifc)
+        res = O.recv_batch(arena, off16, lens, ifc)
+        seen = set(res["verdict"].tolist())
+        want = {6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 18, 19, 20}
+        if ext:
+            want |= {23, 24}
+        assert want <= seen, sorted(want - seen)
+        assert set(np.unique(lens).tolist()) == {64, 576, 1500, 4096, 9000}
+        assert 560 < lens.mean() < 650
+
+
+def test_hdr20_trace_verdicts():
+    n = 4096
+    ifc = unet_amd.Iface()
+    arena, _, lens = unet_amd.synth_host(unet_amd.SYNTH_IPV4_HDR20, SEED, 0, n, ifc)
+    assert (lens == 20).all()
+    res = O.ipv4_validate_batch(arena[:n * 20])
+    seen = set(res["verdict"].tolist())
+    assert {6, 7, 8, 9, 10, 11, 25} <= seen
+    idx = np.arange(n)
+    assert (res["verdict"][idx % 64 == 27] != 25).all()

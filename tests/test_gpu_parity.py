@@ -1,0 +1,391 @@
+"""GPU parity tests: every result of the HIP path is compared bit for bit with the CPU oracle
+(oracle/unet_oracle.c) or with the committed golden vectors.  All calls go through the C ABI."""
+import struct
+
+import numpy as np
+import pytest
+
+import unet_amd
+from unet_amd import Verdict
+from helpers import as_tuples, edge_data, iface_key, load, random_lengths, vector_iface, vector_record
+from oracle import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x756E6574
+KATS = load("reference_kats.json")
+
+
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch
+
+
+def dev(a: np.ndarray):
+    torch = torch_mod()
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def stream():
+    return torch_mod().cuda.current_stream().cuda_stream
+
+
+def results_to_numpy(t):
+    return t.cpu().numpy().view(unet_amd.RESULT_DTYPE).reshape(-1)
+
+
+# ------------------------------------------------------------------ the reference's own tests, on the GPU
+
+def test_calculate_checksum(offload):
+    """src/utils.rs:43-50"""
+    data = bytes.fromhex(KATS["checksum_even"]["data"])
+    s = offload.calculate_checksum(data, 0)
+    assert s == 0xBC58
+    assert offload.calculate_checksum(data, s) == 0
+
+
+def test_calculate_checksum_odd_elements(offload):
+    """src/utils.rs:52-60"""
+    data = bytes.fromhex(KATS["checksum_odd"]["data"])
+    s = offload.calculate_checksum(data, 0)
+    assert s == 0x7C58
+    assert offload.calculate_checksum(data, s) == 0
+
+
+def test_ipv4_header(offload):
+    """src/protocols/ipv4.rs:428-438"""
+    pkt = bytes.fromhex(KATS["ipv4_header"]["packet"])
+    res = offload.ipv4_validate(np.frombuffer(pkt[:20], dtype=np.uint8), unet_amd.Iface())
+    assert as_tuples(res) == [(Verdict.L3_HEADER_OK, 1, 0)]
+    lo = unet_amd.Iface("127.0.0.1", "255.0.0.0")
+    assert as_tuples(offload.verify_frames([pkt], lo)) == [tuple(KATS["ipv4_header"]["recv_verdict"][i] if i else Verdict.ACCEPT_ICMP_ECHO for i in range(3))]
+
+
+def test_parse_icmp_header(offload):
+    """src/transport/icmp.rs:128-139 -- and the checksum icmp::send would have produced for it."""
+    k = KATS["icmp_header"]
+    msg = bytes.fromhex(k["message"])
+    assert offload.calculate_checksum(msg, 0) == 0
+    junk = bytearray(O.create_ip_header(7, 1, 0x7F000001, 0x7F000001, len(msg)) + msg)
+    junk[10:12] = b"\x12\x34"
+    junk[22:24] = b"\x56\x78"
+    arena, off16, lens = unet_amd.pack_arena([bytes(junk)])
+    filled, status = offload.generate(arena, off16, lens)
+    assert status.tolist() == [0]
+    assert filled[22:24].tobytes() == b"\x35\x64"
+    assert filled[:20].tobytes() == O.create_ip_header(7, 1, 0x7F000001, 0x7F000001, len(msg))
+
+
+def test_udp_demo_vector(offload):
+    k = KATS["udp_demo_derived"]
+    seg = bytearray(bytes.fromhex(k["segment"]))
+    seg[6:8] = b"\0\0"
+    pkt = O.create_ip_header(0, 17, 0, 0x7F000001, len(seg)) + bytes(seg)
+    arena, off16, lens = unet_amd.pack_arena([pkt])
+    filled, status = offload.generate(arena, off16, lens)
+    assert status.tolist() == [0] and filled[26:28].tobytes() == b"\x80\x19"
+    lo = unet_amd.Iface("127.0.0.1", "255.0.0.0")
+    assert as_tuples(offload.verify(filled, off16, lens, lo)) == [(Verdict.ACCEPT_UDP, 17, 0)]
+
+
+# ------------------------------------------------------------------ golden vectors
+
+def test_checksum_edge_vectors(offload):
+    vecs = load("checksum_edges.json")["vectors"]
+    datas = [edge_data(e) for e in vecs]
+    arena, off16, lens = unet_amd.pack_arena(datas, pad_byte=0xA7)
+    seeds = np.array([e["seed"] for e in vecs], dtype=np.uint16)
+    got = offload.csum_batch(arena, off16, lens, seeds)
+    assert got.tolist() == [e["ck"] for e in vecs]
+    for e, d in zip(vecs, datas):
+        assert offload.calculate_checksum(d, e["seed"]) == e["ck"], e["name"]
+
+
+def test_verdict_vectors(offload):
+    vecs = load("verdict_vectors.json")["vectors"]
+    groups = {}
+    for v in vecs:
+        groups.setdefault(iface_key(v["iface"]), []).append(v)
+    for vs in groups.values():
+        ifc = vector_iface(vs[0])
+        got = as_tuples(offload.verify_frames([vector_record(v) for v in vs], ifc))
+        for v, g in zip(vs, got):
+            assert g == (v["verdict_code"], v["proto"], v["csum"]), (v["name"], v["verdict"], g)
+
+
+# ------------------------------------------------------------------ a1 on random buffers
+
+def test_csum_batch_random_lengths(offload):
+    rng = np.random.default_rng(11)
+    lens = random_lengths(rng, 6000)
+    lens[-3:] = [65535, 65534, 32769]
+    frames = [rng.integers(0, 256, size=int(n), dtype=np.uint8).tobytes() for n in lens]
+    arena, off16, lens2 = unet_amd.pack_arena(frames, pad_byte=0x5C)
+    seeds = rng.integers(0, 65536, size=len(frames)).astype(np.uint16)
+    got = offload.csum_batch(arena, off16, lens2, seeds)
+    exp = O.csum_batch(arena, off16, lens2, seeds)
+    assert (got == exp).all()
+    # no seeds, and every result chained into a second pass gives zero (the reference's test idiom)
+    s0 = offload.csum_batch(arena, off16, lens2)
+    assert (s0 == O.csum_batch(arena, off16, lens2)).all()
+    assert not offload.csum_batch(arena, off16, lens2, s0)[lens2 > 0].any()
+
+
+def test_csum_batch_fixed_stride(offload):
+    rng = np.random.default_rng(12)
+    n, stride16 = 1000, 7
+    arena = rng.integers(0, 256, size=n * stride16 * 16, dtype=np.uint8)
+    lens = rng.integers(0, stride16 * 16 + 1, size=n).astype(np.uint32)
+    got = offload.csum_batch(arena, None, lens, None, stride16=stride16)
+    assert (got == O.csum_batch(arena, None, lens, None, stride16=stride16)).all()
+
+
+# ------------------------------------------------------------------ synthetic traces: device == host twin, GPU == oracle
+
+@pytest.mark.parametrize("kind,n", [(unet_amd.SYNTH_UDP1500, 3000), (unet_amd.SYNTH_IMIX, 20000)])
+@pytest.mark.parametrize("ext_tcp", [False, True])
+def test_trace_generator_and_verify(offload, kind, n, ext_tcp):
+    torch = torch_mod()
+    ifc = unet_amd.Iface(ext_tcp=ext_tcp)
+    first = 12345
+    h_arena, off16, lens = unet_amd.synth_host(kind, SEED, first, n, ifc)
+    d_off, d_len = dev(off16), dev(lens)
+    d_arena = torch.full((h_arena.nbytes,), 0xEE, dtype=torch.uint8, device="cuda")
+    offload.synth_dev(kind, SEED, first, n, ifc, d_off.data_ptr(), d_len.data_ptr(), d_arena.data_ptr(), h_arena.nbytes, stream())
+    torch.cuda.synchronize()
+    assert (d_arena.cpu().numpy() == h_arena).all(), "device generator and host twin disagree"
+    d_out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    offload.verify_dev(d_arena.data_ptr(), h_arena.nbytes, d_off.data_ptr(), 0, d_len.data_ptr(), n, ifc, d_out.data_ptr(), stream())
+    torch.cuda.synchronize()
+    got = results_to_numpy(d_out)
+    exp = O.recv_batch(h_arena, off16, lens, ifc)
+    bad = np.nonzero(got != exp)[0]
+    assert bad.size == 0, (bad[:5], got[bad[:5]], exp[bad[:5]], lens[bad[:5]])
+    # histogram kernel
+    d_cnt = torch.zeros(32, dtype=torch.int64, device="cuda")
+    offload.count_verdicts_dev(d_out.data_ptr(), n, d_cnt.data_ptr(), stream())
+    torch.cuda.synchronize()
+    assert d_cnt.cpu().numpy().tolist() == np.bincount(exp["verdict"], minlength=32).tolist()
+    # the host-pointer entry point gives the same answers
+    got_h = offload.verify(h_arena, off16, lens, ifc)
+    assert (got_h == exp).all()
+    if kind == unet_amd.SYNTH_UDP1500:
+        got_s = offload.verify(h_arena, None, lens, ifc, stride16=94)
+        assert (got_s == exp).all()
+
+
+def l2_wrap(records, ifc, rng):
+    """Ethernet-frame the L3 records: mostly for us, some broadcast, some foreign MAC, a few ARP/IPv6/runt."""
+    out = []
+    for r in records:
+        t = rng.integers(0, 40)
+        dst = ifc.mac if t < 30 else (b"\xff" * 6 if t < 34 else bytes(rng.integers(0, 256, size=6, dtype=np.uint8)))
+        et = 0x0800 if t % 10 else (0x0806 if t % 20 else 0x86DD)
+        fr = dst + b"\x02\x11\x22\x33\x44\x55" + struct.pack(">H", et) + r
+        if t == 39:
+            fr = fr[:int(rng.integers(0, 14))]
+        if t == 38:
+            fr = fr[:int(rng.integers(14, 40))]
+        out.append(fr)
+    return out
+
+
+@pytest.mark.parametrize("ext_tcp", [False, True])
+def test_l2_mode_random_frames(offload, ext_tcp):
+    rng = np.random.default_rng(21)
+    ifc3 = unet_amd.Iface(ext_tcp=ext_tcp)
+    n = 6000
+    arena, off16, lens = unet_amd.synth_host(unet_amd.SYNTH_IMIX, SEED, 777, n, ifc3)
+    recs = [arena[int(o) * 16:int(o) * 16 + int(l)].tobytes() for o, l in zip(off16, lens)]
+    ifc2 = ifc3.replace(mode=unet_amd.MODE_L2, mac=b"\x02\x00\x5e\x10\x20\x30")
+    frames = l2_wrap(recs, ifc2, rng)
+    a2, o2, l2 = unet_amd.pack_arena(frames, pad_byte=0x3D)
+    got = offload.verify(a2, o2, l2, ifc2)
+    exp = O.recv_batch(a2, o2, l2, ifc2)
+    bad = np.nonzero(got != exp)[0]
+    assert bad.size == 0, (bad[:5], got[bad[:5]], exp[bad[:5]], l2[bad[:5]])
+    assert {1, 2, 3, 4} <= set(exp["verdict"].tolist())
+
+
+def test_mutated_records_against_oracle(offload):
+    """Random corruption of valid records: header nibbles, lengths, truncation at every offset."""
+    rng = np.random.default_rng(31)
+    ifc = unet_amd.Iface(ext_tcp=True)
+    arena, off16, lens = unet_amd.synth_host(unet_amd.SYNTH_IMIX, SEED, 0, 3000, ifc)
+    recs = []
+    for o, l in zip(off16, lens):
+        r = bytearray(arena[int(o) * 16:int(o) * 16 + int(l)].tobytes())
+        if len(r) > 1500:
+            continue
+        m = rng.integers(0, 6)
+        if m == 0:
+            r = r[:int(rng.integers(0, min(len(r), 80)))]
+        elif m == 1:
+            pos = int(rng.integers(0, min(len(r), 64)))
+            r[pos] ^= 1 << int(rng.integers(0, 8))
+        elif m == 2:
+            r += bytes(int(rng.integers(1, 20)))
+        elif m == 3:
+            r[0] = (r[0] & 0xF0) | int(rng.integers(0, 16))
+        elif m == 4 and len(r) > 40:
+            r[9] = int(rng.choice([1, 6, 17]))
+        recs.append(bytes(r))
+    a2, o2, l2 = unet_amd.pack_arena(recs, pad_byte=0x99)
+    for ext in (True, False):
+        i2 = ifc.replace(ext_tcp=ext)
+        got = offload.verify(a2, o2, l2, i2)
+        exp = O.recv_batch(a2, o2, l2, i2)
+        bad = np.nonzero(got != exp)[0]
+        assert bad.size == 0, (bad[:5], got[bad[:5]], exp[bad[:5]], l2[bad[:5]])
+
+
+# ------------------------------------------------------------------ a2-a4: bare headers
+
+@pytest.mark.parametrize("n", [1, 63, 1024, 1025, 100003])
+@pytest.mark.parametrize("ext_tcp", [False, True])
+def test_ipv4_validate_headers(offload, n, ext_tcp):
+    ifc = unet_amd.Iface(ext_tcp=ext_tcp)
+    arena, _, _ = unet_amd.synth_host(unet_amd.SYNTH_IPV4_HDR20, SEED, 5, n, ifc)
+    got = offload.ipv4_validate(arena[:n * 20], ifc)
+    exp = O.ipv4_validate_batch(arena[:n * 20], ext_tcp)
+    assert (got == exp).all()
+
+
+def test_ipv4_validate_device_generated(offload):
+    torch = torch_mod()
+    ifc = unet_amd.Iface()
+    n = 300007
+    h_arena, _, _ = unet_amd.synth_host(unet_amd.SYNTH_IPV4_HDR20, SEED, 0, n, ifc)
+    d_arena = torch.zeros(h_arena.nbytes, dtype=torch.uint8, device="cuda")
+    offload.synth_dev(unet_amd.SYNTH_IPV4_HDR20, SEED, 0, n, ifc, None, None, d_arena.data_ptr(), h_arena.nbytes, stream())
+    torch.cuda.synchronize()
+    assert (d_arena.cpu().numpy()[:n * 20] == h_arena[:n * 20]).all()
+    d_out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    offload.ipv4_validate_dev(d_arena.data_ptr(), n, ifc, d_out.data_ptr(), stream())
+    torch.cuda.synchronize()
+    assert (results_to_numpy(d_out) == O.ipv4_validate_batch(h_arena[:n * 20])).all()
+
+
+# ------------------------------------------------------------------ a7, a9, a10: transmit side
+
+def test_generate_matches_oracle_and_roundtrips(offload):
+    rng = np.random.default_rng(41)
+    tap = unet_amd.Iface()
+    frames = []
+    for i in range(3000):
+        n = int(rng.choice([8, 9, 12, 36, 37, 100, 1000, 1472, 1480, 4000, 8972])) if i % 4 else int(rng.integers(0, 1481))
+        proto = [17, 1, 17, 6][i % 4] if i % 97 else 47
+        hdr = bytearray(O.create_ip_header(i & 0xFFFF, proto if proto != 47 else 17, 0x0A000001, tap.unicast, n))
+        hdr[9] = proto
+        hdr[10:12] = rng.integers(0, 256, size=2, dtype=np.uint8).tobytes()
+        if i % 53 == 0:
+            hdr[0] = 0x46
+        body = bytearray(rng.integers(0, 256, size=n, dtype=np.uint8).tobytes())
+        if proto == 17 and n >= 8:
+            body[4:6] = struct.pack(">H", n)
+        if proto == 1 and n >= 1:
+            body[0] = 8 if i % 8 else 0
+        frames.append(bytes(hdr) + bytes(body))
+    arena, off16, lens = unet_amd.pack_arena(frames, pad_byte=0x42)
+    got_arena, got_status = offload.generate(arena, off16, lens)
+    exp_arena, exp_status = O.generate_batch(arena, off16, lens)
+    assert (got_status == exp_status).all()
+    assert (got_arena == exp_arena).all()
+    res = offload.verify(got_arena, off16, lens, tap)
+    filled = got_status == 0
+    assert filled.sum() > 2000
+    assert set(res["verdict"][filled].tolist()) <= {Verdict.ACCEPT_UDP, Verdict.ACCEPT_ICMP_ECHO, Verdict.ACCEPT_ICMP_ECHOREPLY}
+
+
+# ------------------------------------------------------------------ flow hash
+
+def test_flow_hash_matches_oracle(offload):
+    torch = torch_mod()
+    ifc = unet_amd.Iface(ext_tcp=True)
+    n = 5000
+    h_arena, off16, lens = unet_amd.synth_host(unet_amd.SYNTH_IMIX, SEED, 99, n, ifc)
+    d_arena, d_off, d_len = dev(h_arena), dev(off16), dev(lens)
+    d_hash = torch.zeros(n, dtype=torch.int32, device="cuda")
+    offload.flow_hash_dev(d_arena.data_ptr(), h_arena.nbytes, d_off.data_ptr(), 0, d_len.data_ptr(), n, ifc, d_hash.data_ptr(), stream())
+    torch.cuda.synchronize()
+    got = d_hash.cpu().numpy().view(np.uint32)
+    exp = np.array([O.flow_hash_record(h_arena[int(o) * 16:int(o) * 16 + int(l)].tobytes(), ifc) for o, l in zip(off16, lens)], dtype=np.uint32)
+    assert (got == exp).all()
+
+
+# ------------------------------------------------------------------ argument checking
+
+def test_bad_arguments_are_rejected(offload):
+    torch = torch_mod()
+    ifc = unet_amd.Iface()
+    arena = np.zeros(64, dtype=np.uint8)
+    with pytest.raises(unet_amd.UnetError) as ei:
+        offload.verify(arena, np.array([0], dtype=np.uint32), np.array([70000], dtype=np.uint32), ifc)
+    assert ei.value.code == -5
+    with pytest.raises(unet_amd.UnetError) as ei:
+        offload.verify(arena, np.array([3], dtype=np.uint32), np.array([40], dtype=np.uint32), ifc)
+    assert ei.value.code == -5
+    d = torch.zeros(256, dtype=torch.uint8, device="cuda")
+    d_len = dev(np.array([20], dtype=np.uint32))
+    d_out = torch.zeros(1, dtype=torch.int32, device="cuda")
+    with pytest.raises(unet_amd.UnetError) as ei:
+        offload.verify_dev(d.data_ptr() + 4, 128, None, 2, d_len.data_ptr(), 1, ifc, d_out.data_ptr(), stream())
+    assert ei.value.code == -1
+    # device tables the host cannot inspect: out-of-range records come back as V_NONE, nothing is read
+    d_len2 = dev(np.array([20, 70000, 40], dtype=np.uint32))
+    d_off2 = dev(np.array([0, 0, 15], dtype=np.uint32))
+    d_out2 = torch.full((3,), -1, dtype=torch.int32, device="cuda")
+    offload.verify_dev(d.data_ptr(), 256, d_off2.data_ptr(), 0, d_len2.data_ptr(), 3, ifc, d_out2.data_ptr(), stream())
+    torch.cuda.synchronize()
+    r = results_to_numpy(d_out2)
+    assert r["verdict"].tolist()[1:] == [0, 0] and r["verdict"][0] != 0
+
+
+# ------------------------------------------------------------------ full-size configurations (properties)
+
+def test_full_size_udp1500_batch_properties(offload):
+    """4,194,304 x 1500-byte UDP packets generated in HBM: verdict counts follow from the per-index fault
+    rules, and a window regenerated on the host matches the oracle record for record."""
+    torch = torch_mod()
+    ifc = unet_amd.Iface()
+    n, stride16 = 1 << 22, 94
+    nbytes = n * stride16 * 16
+    d_len = torch.full((n,), 1500, dtype=torch.int32, device="cuda")
+    d_off = (torch.arange(n, dtype=torch.int64, device="cuda") * stride16).to(torch.int32)
+    d_arena = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    offload.synth_dev(unet_amd.SYNTH_UDP1500, SEED, 0, n, ifc, d_off.data_ptr(), d_len.data_ptr(), d_arena.data_ptr(), nbytes, stream())
+    d_out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    offload.verify_dev(d_arena.data_ptr(), nbytes, None, stride16, d_len.data_ptr(), n, ifc, d_out.data_ptr(), stream())
+    d_cnt = torch.zeros(32, dtype=torch.int64, device="cuda")
+    offload.count_verdicts_dev(d_out.data_ptr(), n, d_cnt.data_ptr(), stream())
+    torch.cuda.synchronize()
+    cnt = d_cnt.cpu().numpy()
+    n_len = n // 256
+    n_csum = n // 64 + n // 256
+    assert cnt[Verdict.DROP_UDP_LEN] == n_len
+    # a flipped bit always breaks the sum; a zeroed checksum field breaks it unless the right value was 0
+    assert n_csum - 8 <= cnt[Verdict.DROP_UDP_CSUM] <= n_csum
+    assert cnt[Verdict.ACCEPT_UDP] == n - n_len - cnt[Verdict.DROP_UDP_CSUM]
+    assert cnt.sum() == n
+    w0, wn = 3_000_000, 4096
+    h_arena, off16, lens = unet_amd.synth_host(unet_amd.SYNTH_UDP1500, SEED, w0, wn, ifc)
+    assert (d_arena[w0 * stride16 * 16:(w0 + wn) * stride16 * 16].cpu().numpy() == h_arena).all()
+    exp = O.recv_batch(h_arena, off16, lens, ifc)
+    assert (results_to_numpy(d_out[w0:w0 + wn]) == exp).all()
+
+
+def test_full_size_header_batch(offload):
+    """16,777,216 bare headers: every result compared with the oracle."""
+    torch = torch_mod()
+    ifc = unet_amd.Iface()
+    n = 1 << 24
+    h_arena, _, _ = unet_amd.synth_host(unet_amd.SYNTH_IPV4_HDR20, SEED, 0, n, ifc)
+    d_arena = torch.zeros(h_arena.nbytes, dtype=torch.uint8, device="cuda")
+    offload.synth_dev(unet_amd.SYNTH_IPV4_HDR20, SEED, 0, n, ifc, None, None, d_arena.data_ptr(), h_arena.nbytes, stream())
+    d_out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    offload.ipv4_validate_dev(d_arena.data_ptr(), n, ifc, d_out.data_ptr(), stream())
+    torch.cuda.synchronize()
+    assert (d_arena.cpu().numpy()[:n * 20] == h_arena[:n * 20]).all()
+    exp = O.ipv4_validate_batch(h_arena[:n * 20])
+    assert (results_to_numpy(d_out) == exp).all()

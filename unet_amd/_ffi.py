@@ -1,0 +1,335 @@
+"""ctypes binding of libunet_offload.so (include/unet_offload.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import os
+from typing import Iterable, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libunet_offload.so")
+
+RESULT_DTYPE = np.dtype([("csum", "<u2"), ("verdict", "u1"), ("proto", "u1")])
+
+
+class UnetError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"unet_offload error {code}: {msg}")
+        self.code = code
+
+
+class Verdict(enum.IntEnum):
+    NONE = 0
+    DROP_L2_TRUNCATED = 1
+    DROP_L2_ETHERTYPE = 2
+    DROP_L2_NOT_FOR_ME = 3
+    PASS_ARP = 4
+    DROP_L3_TRUNCATED = 5
+    DROP_L3_PROTO = 6
+    DROP_L3_VERSION = 7
+    DROP_L3_IHL_SHORT = 8
+    DROP_L3_IHL_LONG = 9
+    DROP_L3_FRAGMENT = 10
+    DROP_L3_CSUM = 11
+    IGNORE_L3_NOT_FOR_ME = 12
+    DROP_ICMP_TRUNCATED = 13
+    DROP_ICMP_TYPE = 14
+    ACCEPT_ICMP_ECHO = 15
+    ACCEPT_ICMP_ECHOREPLY = 16
+    DROP_UDP_SHORT = 17
+    DROP_UDP_LEN = 18
+    DROP_UDP_CSUM = 19
+    ACCEPT_UDP = 20
+    DROP_TCP_SHORT = 21
+    DROP_TCP_DOFF = 22
+    DROP_TCP_CSUM = 23
+    ACCEPT_TCP = 24
+    L3_HEADER_OK = 25
+
+
+V_COUNT = 32
+
+
+class _IfaceC(C.Structure):
+    _fields_ = [
+        ("unicast", C.c_uint32),
+        ("broadcast", C.c_uint32),
+        ("mac", C.c_uint8 * 6),
+        ("mode", C.c_uint8),
+        ("ext_tcp", C.c_uint8),
+    ]
+
+
+def _ip(addr) -> int:
+    if isinstance(addr, int):
+        return addr & 0xFFFFFFFF
+    a, b, c, d = (int(x) for x in str(addr).split("."))
+    return (a << 24) | (b << 16) | (c << 8) | d
+
+
+class Iface:
+    """Receiving interface constants (Ipv4Interface::new, src/protocols/ipv4.rs:218-229)."""
+
+    def __init__(self, unicast="192.0.2.2", netmask="255.255.255.0", mac=b"\x02\x00\x00\x00\x00\x01",
+                 mode: int = 0, ext_tcp: bool = False):
+        self.unicast = _ip(unicast)
+        self.netmask = _ip(netmask)
+        self.broadcast = (self.unicast & 0xFFFFFF00) | (~self.netmask & 0xFF)
+        self.mac = bytes(mac)
+        assert len(self.mac) == 6
+        self.mode = int(mode)
+        self.ext_tcp = bool(ext_tcp)
+
+    def c(self) -> _IfaceC:
+        s = _IfaceC()
+        s.unicast = self.unicast
+        s.broadcast = self.broadcast
+        for i, b in enumerate(self.mac):
+            s.mac[i] = b
+        s.mode = self.mode
+        s.ext_tcp = 1 if self.ext_tcp else 0
+        return s
+
+    def replace(self, **kw) -> "Iface":
+        o = Iface.__new__(Iface)
+        o.__dict__.update(self.__dict__)
+        o.__dict__.update(kw)
+        return o
+
+
+_lib = None
+
+_vp, _u8p, _u16p, _u32p, _u64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+
+_SIGS = {
+    "unet_open": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "unet_close": (None, [C.c_void_p]),
+    "unet_last_error": (C.c_char_p, []),
+    "unet_device_count": (C.c_int, []),
+    "unet_sync": (C.c_int, [C.c_void_p]),
+    "unet_csum_batch_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, _u16p, C.c_uint32, _u16p]),
+    "unet_csum_batch": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, _u16p, C.c_uint32, _u16p]),
+    "unet_csum": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.c_uint16, C.POINTER(C.c_uint16)]),
+    "unet_ipv4_validate_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
+    "unet_ipv4_validate": (C.c_int, [_vp, _u8p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
+    "unet_verify_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
+    "unet_verify": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
+    "unet_generate_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, _u8p]),
+    "unet_generate": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, _u8p]),
+    "unet_count_verdicts_dev": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _u64p]),
+    "unet_flow_hash5": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint16, C.c_uint16]),
+    "unet_flow_hash_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _u32p]),
+    "unet_synth_len": (C.c_uint32, [C.c_int, C.c_uint64, C.c_uint64]),
+    "unet_synth_layout": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, _u32p, _u32p, C.POINTER(C.c_uint64)]),
+    "unet_synth_host": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(_IfaceC), _u32p, _u32p, _u8p, C.c_uint64]),
+    "unet_synth_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(_IfaceC), _u32p, _u32p, _u8p, C.c_uint64]),
+    "unet_stream_read_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen the offload library; raises if it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise FileNotFoundError(
+            f"{p} not found: build it with `python __graft_entry__.py build` (hipcc --offload-arch=gfx950); "
+            "there is no CPU fallback for the offload")
+    lib = C.CDLL(p)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError here means the ABI and the header disagree
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise UnetError(rc, load_library().unet_last_error().decode(errors="replace"))
+
+
+def _np_ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data
+
+
+def pack_arena(frames: Iterable[bytes], pad_byte: int = 0xEE) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Arena packer: every record starts on a 16-byte boundary; pad bytes are arbitrary (0xEE)."""
+    frames = [bytes(f) for f in frames]
+    lens = np.array([len(f) for f in frames], dtype=np.uint32)
+    slots = (lens.astype(np.uint64) + 15) // 16
+    off16 = np.zeros(len(frames), dtype=np.uint32)
+    if len(frames):
+        off16[1:] = np.cumsum(slots)[:-1].astype(np.uint32)
+    total = int(slots.sum()) * 16
+    arena = np.full(max(total, 16), pad_byte, dtype=np.uint8)
+    for f, o in zip(frames, off16):
+        arena[int(o) * 16:int(o) * 16 + len(f)] = np.frombuffer(f, dtype=np.uint8)
+    return arena, off16, lens
+
+
+def _aligned_u8(nbytes: int) -> np.ndarray:
+    raw = np.empty(nbytes + 16, dtype=np.uint8)
+    shift = (-raw.ctypes.data) % 16
+    return raw[shift:shift + nbytes]
+
+
+def synth_len(kind: int, seed: int, idx: int) -> int:
+    return int(load_library().unet_synth_len(kind, seed, idx))
+
+
+def synth_layout(kind: int, seed: int, first_idx: int, n: int):
+    off16 = np.zeros(n, dtype=np.uint32)
+    lens = np.zeros(n, dtype=np.uint32)
+    nbytes = C.c_uint64(0)
+    _check(load_library().unet_synth_layout(kind, seed, first_idx, n, _np_ptr(off16), _np_ptr(lens), C.byref(nbytes)))
+    return off16, lens, int(nbytes.value)
+
+
+def synth_host(kind: int, seed: int, first_idx: int, n: int, iface: Iface):
+    """Host twin of the device trace generator -> (arena, off16, lens)."""
+    off16, lens, nbytes = synth_layout(kind, seed, first_idx, n)
+    arena = _aligned_u8(max(nbytes, 16))
+    arena[:] = 0xEE
+    ic = iface.c()
+    _check(load_library().unet_synth_host(kind, seed, first_idx, n, C.byref(ic), _np_ptr(off16), _np_ptr(lens),
+                                          _np_ptr(arena), nbytes))
+    return arena, off16, lens
+
+
+def flow_hash5(src: int, dst: int, proto: int, sport: int, dport: int) -> int:
+    return int(load_library().unet_flow_hash5(src, dst, proto, sport, dport))
+
+
+class Offload:
+    """One context on one GPU.  Host-pointer methods take numpy arrays; ``*_dev`` methods take raw
+    device pointers (ints, e.g. ``tensor.data_ptr()``) and enqueue on ``stream`` without waiting."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        _check(self.lib.unet_open(device, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.unet_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _check(self.lib.unet_sync(self.h))
+
+    # -- a1 ---------------------------------------------------------------------------------
+    def calculate_checksum(self, data: bytes, sum: int = 0) -> int:
+        """`calculate_checksum(data, sum)` of src/utils.rs:1, computed on the GPU."""
+        out = C.c_uint16(0)
+        data = bytes(data)
+        _check(self.lib.unet_csum(self.h, data, len(data), sum & 0xFFFF, C.byref(out)))
+        return int(out.value)
+
+    def csum_batch(self, arena: np.ndarray, off16, lens: np.ndarray, seeds=None, stride16: int = 0) -> np.ndarray:
+        arena, off16, lens = self._prep(arena, off16, lens)
+        n = len(lens)
+        out = np.zeros(n, dtype=np.uint16)
+        if seeds is not None:
+            seeds = np.ascontiguousarray(seeds, dtype=np.uint16)
+        _check(self.lib.unet_csum_batch(self.h, _np_ptr(arena), arena.nbytes, _np_ptr(off16), stride16, _np_ptr(lens),
+                                        _np_ptr(seeds), n, _np_ptr(out)))
+        return out
+
+    # -- a2-a4 ------------------------------------------------------------------------------
+    def ipv4_validate(self, hdrs: np.ndarray, iface: Iface) -> np.ndarray:
+        hdrs = np.ascontiguousarray(hdrs, dtype=np.uint8).reshape(-1)
+        assert hdrs.size % 20 == 0
+        n = hdrs.size // 20
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        ic = iface.c()
+        _check(self.lib.unet_ipv4_validate(self.h, _np_ptr(hdrs), n, C.byref(ic), _np_ptr(out)))
+        return out
+
+    # -- receive path -----------------------------------------------------------------------
+    def verify(self, arena: np.ndarray, off16, lens: np.ndarray, iface: Iface, stride16: int = 0) -> np.ndarray:
+        arena, off16, lens = self._prep(arena, off16, lens)
+        n = len(lens)
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        ic = iface.c()
+        _check(self.lib.unet_verify(self.h, _np_ptr(arena), arena.nbytes, _np_ptr(off16), stride16, _np_ptr(lens), n,
+                                    C.byref(ic), _np_ptr(out)))
+        return out
+
+    def verify_frames(self, frames: Sequence[bytes], iface: Iface) -> np.ndarray:
+        arena, off16, lens = pack_arena(frames)
+        return self.verify(arena, off16, lens, iface)
+
+    # -- transmit path ----------------------------------------------------------------------
+    def generate(self, arena: np.ndarray, off16, lens: np.ndarray, stride16: int = 0):
+        """Returns (filled copy of the arena, status)."""
+        arena, off16, lens = self._prep(arena, off16, lens)
+        arena = arena.copy()
+        n = len(lens)
+        status = np.zeros(n, dtype=np.uint8)
+        _check(self.lib.unet_generate(self.h, _np_ptr(arena), arena.nbytes, _np_ptr(off16), stride16, _np_ptr(lens), n,
+                                      _np_ptr(status)))
+        return arena, status
+
+    # -- device-pointer entry points ----------------------------------------------------------
+    def csum_batch_dev(self, d_arena, arena_bytes, d_off16, stride16, d_len, d_seeds, n, d_out, stream=None):
+        _check(self.lib.unet_csum_batch_dev(self.h, stream, d_arena, arena_bytes, d_off16, stride16, d_len, d_seeds, n, d_out))
+
+    def verify_dev(self, d_arena, arena_bytes, d_off16, stride16, d_len, n, iface: Iface, d_out, stream=None):
+        ic = iface.c()
+        _check(self.lib.unet_verify_dev(self.h, stream, d_arena, arena_bytes, d_off16, stride16, d_len, n, C.byref(ic), d_out))
+
+    def ipv4_validate_dev(self, d_hdrs, n, iface: Iface, d_out, stream=None):
+        ic = iface.c()
+        _check(self.lib.unet_ipv4_validate_dev(self.h, stream, d_hdrs, n, C.byref(ic), d_out))
+
+    def generate_dev(self, d_arena, arena_bytes, d_off16, stride16, d_len, n, d_status, stream=None):
+        _check(self.lib.unet_generate_dev(self.h, stream, d_arena, arena_bytes, d_off16, stride16, d_len, n, d_status))
+
+    def count_verdicts_dev(self, d_results, n, d_counts, stream=None):
+        _check(self.lib.unet_count_verdicts_dev(self.h, stream, d_results, n, d_counts))
+
+    def flow_hash_dev(self, d_arena, arena_bytes, d_off16, stride16, d_len, n, iface: Iface, d_hash, stream=None):
+        ic = iface.c()
+        _check(self.lib.unet_flow_hash_dev(self.h, stream, d_arena, arena_bytes, d_off16, stride16, d_len, n, C.byref(ic), d_hash))
+
+    def synth_dev(self, kind, seed, first_idx, n, iface: Iface, d_off16, d_len, d_arena, arena_bytes, stream=None):
+        ic = iface.c()
+        _check(self.lib.unet_synth_dev(self.h, stream, kind, seed, first_idx, n, C.byref(ic), d_off16, d_len, d_arena, arena_bytes))
+
+    def stream_read_dev(self, d_buf, nbytes, d_sink, stream=None):
+        _check(self.lib.unet_stream_read_dev(self.h, stream, d_buf, nbytes, d_sink))
+
+    # -- helpers --------------------------------------------------------------------------------
+    @staticmethod
+    def _prep(arena, off16, lens):
+        arena = np.ascontiguousarray(arena, dtype=np.uint8)
+        if arena.ctypes.data % 16:
+            a2 = _aligned_u8(arena.nbytes)
+            a2[:] = arena
+            arena = a2
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        if off16 is not None:
+            off16 = np.ascontiguousarray(off16, dtype=np.uint32)
+        return arena, off16, lens

@@ -1,0 +1,393 @@
+// gfx950 kernels of the offload.  All of them are HBM-bound byte/integer work: 16-byte
+// coalesced loads, one v_sad_u16 per dword, DPP wave reductions, no LDS except where a
+// record is not a multiple of 16 bytes (the bare 20-byte header kernel).
+#pragma once
+#include "csum_core.h"
+#include "parse.h"
+#include "synth_spec.h"
+
+namespace unetdev {
+
+constexpr u32 kTile = 64;        // records per wave: lane j keeps record j's metadata and result
+constexpr u32 kBlock = 256;      // 4 waves
+constexpr u32 kMaxLen = 65535;   // IPv4 maximum (src/protocols/ipv4.rs:18), loopback MTU (src/devices/loopback.rs:16)
+
+// Where the records of a batch live.
+struct Batch {
+    const uint8_t* arena;
+    u64 arena_bytes;
+    const u32* off16;  // may be null: fixed stride
+    u32 stride16;
+    const u32* len;
+    u32 n;
+};
+
+// Header dwords of the record a wave is working on, held in row 0 (chunk `lane` of the record).
+struct WaveFetch {
+    u32x4 r;
+    __device__ __forceinline__ u32 operator()(u32 k) const {
+        const u32 l = k >> 2, s = k & 3u;
+        const u32 x = rdlane(r.x, l), y = rdlane(r.y, l), z = rdlane(r.z, l), w = rdlane(r.w, l);
+        return s == 0u ? x : (s == 1u ? y : (s == 2u ? z : w));
+    }
+};
+
+// Per-lane tail masking of the last 16-byte chunk of a record (bytes at and beyond `flen` are
+// pad and must not be summed).  m[] are wave-uniform.
+struct TailMask {
+    u32 last;  // index of the last chunk
+    u32 m0, m1, m2, m3;
+    __device__ __forceinline__ TailMask(u32 flen, u32 nch) {
+        last = nch - 1u;
+        const int tb = (int)(flen - last * 16u);  // 1..16 valid bytes in the last chunk
+        m0 = keep_bytes(tb);
+        m1 = keep_bytes(tb - 4);
+        m2 = keep_bytes(tb - 8);
+        m3 = keep_bytes(tb - 12);
+    }
+    __device__ __forceinline__ u32x4 apply(u32x4 v, u32 chunk) const {
+        if (chunk == last) {
+            v.x &= m0;
+            v.y &= m1;
+            v.z &= m2;
+            v.w &= m3;
+        }
+        return v;
+    }
+};
+
+// Exact byte-swapped-word sum of record [0, flen) given row 0 already loaded; wave-uniform result.
+// `p` points at the record, `nch` = ceil(flen / 16).
+__device__ __forceinline__ u32 record_sum(const u32x4* __restrict__ p, u32 flen, u32 nch, u32x4 row0, u32 lane) {
+    const TailMask tm(flen, nch);
+    u32 acc = sum_chunk(tm.apply(row0, lane), 0u);
+    for (u32 c0 = kWave; c0 < nch; c0 += 4u * kWave) {
+        const u32 i0 = c0 + lane, i1 = i0 + kWave, i2 = i1 + kWave, i3 = i2 + kWave;
+        u32x4 a = {0, 0, 0, 0}, b = a, c = a, d = a;
+        if (i0 < nch) a = p[i0];
+        if (i1 < nch) b = p[i1];
+        if (i2 < nch) c = p[i2];
+        if (i3 < nch) d = p[i3];
+        acc = sum_chunk(tm.apply(a, i0), acc);
+        acc = sum_chunk(tm.apply(b, i1), acc);
+        acc = sum_chunk(tm.apply(c, i2), acc);
+        acc = sum_chunk(tm.apply(d, i3), acc);
+    }
+    return wave_sum(acc);
+}
+
+// Tile bookkeeping shared by the wave-per-record kernels.
+struct Tile {
+    u32 first, cnt, lane;
+    u32 my_len, my_slot;
+    bool my_ok;
+    __device__ __forceinline__ bool init(const Batch& b) {
+        lane = threadIdx.x & 63u;
+        const u32 wave = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+        first = wave * kTile;
+        if (first >= b.n) return false;
+        cnt = min(kTile, b.n - first);
+        my_len = 0;
+        my_slot = 0;
+        my_ok = false;
+        if (lane < cnt) {
+            const u32 i = first + lane;
+            my_len = b.len[i];
+            my_slot = b.off16 ? b.off16[i] : i * b.stride16;
+            // the record and its pad to 16 bytes must lie inside the arena
+            const u64 end = (u64)my_slot * 16u + (((u64)my_len + 15u) & ~15ull);
+            my_ok = my_len <= kMaxLen && end <= b.arena_bytes;
+        }
+        return true;
+    }
+};
+
+// ---------------------------------------------------------------- a1: calculate_checksum
+// out[i] = calculate_checksum(record i, seeds[i])  (src/utils.rs:1-17)
+__global__ __launch_bounds__(kBlock) void k_csum(Batch b, const uint16_t* __restrict__ seeds,
+                                                 uint16_t* __restrict__ out) {
+    Tile t;
+    if (!t.init(b)) return;
+    u32 my_seed = 0;
+    if (seeds && t.lane < t.cnt) my_seed = seeds[t.first + t.lane];
+    const u64 okmask = __ballot(t.my_ok);
+    u32 my_res = 0;
+    for (u32 j = 0; j < t.cnt; ++j) {
+        const u32 flen = rdlane(t.my_len, j);
+        const u32 slot = rdlane(t.my_slot, j);
+        const u32 seed = rdlane(my_seed, j);
+        if (!((okmask >> j) & 1ull)) continue;
+        u32 total = 0;
+        if (flen != 0u) {
+            const u32x4* p = reinterpret_cast<const u32x4*>(b.arena + (u64)slot * 16u);
+            const u32 nch = (flen + 15u) >> 4;
+            u32x4 r0 = {0, 0, 0, 0};
+            if (t.lane < nch) r0 = p[t.lane];
+            total = record_sum(p, flen, nch, r0, t.lane);
+        }
+        const u32 res = finish(total + bswap16(seed));
+        if (t.lane == j) my_res = res;
+    }
+    if (t.lane < t.cnt) out[t.first + t.lane] = (uint16_t)my_res;
+}
+
+// ------------------------------------------- a2-a6, a8, a11: receive-path verdicts
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_verify(Batch b, IfaceDev ifc, u32* __restrict__ out) {
+    Tile t;
+    if (!t.init(b)) return;
+    const u64 okmask = __ballot(t.my_ok);
+    u32 my_res = 0;  // V_NONE for records whose length/offset is out of range
+    for (u32 j = 0; j < t.cnt; ++j) {
+        const u32 flen = rdlane(t.my_len, j);
+        const u32 slot = rdlane(t.my_slot, j);
+        if (!((okmask >> j) & 1ull)) continue;
+        const u32x4* p = reinterpret_cast<const u32x4*>(b.arena + (u64)slot * 16u);
+        const u32 nch = (flen + 15u) >> 4;
+        WaveFetch f;
+        f.r = u32x4{0, 0, 0, 0};
+        if (t.lane < nch) f.r = p[t.lane];
+        const Parsed P = parse_record<MODE>(f, flen, ifc);
+        u32 res = P.res;
+        if (P.kind != K_DONE) {  // wave-uniform: records dropped on their headers are not summed
+            const u32 total = record_sum(p, flen, nch, f.r, t.lane);
+            res = finalize_record(P, total);
+        }
+        if (t.lane == j) my_res = res;
+    }
+    if (t.lane < t.cnt) out[t.first + t.lane] = my_res;
+}
+
+// ------------------------------------ a2-a4: Ipv4Header::try_from + validate, bare headers
+// 20-byte records back to back.  A block stages kHdrPerBlock headers (a multiple of 16 bytes)
+// through LDS with 16-byte coalesced loads; each thread then reads its headers as 5 dwords at a
+// 5-dword stride (odd stride: conflict-free on the 32-bank ds_read_b32 path).
+constexpr u32 kHdrPerThread = 4;
+constexpr u32 kHdrPerBlock = kBlock * kHdrPerThread;       // 1024 headers = 20480 bytes
+constexpr u32 kHdrChunksPerBlock = kHdrPerBlock * 20 / 16;  // 1280 chunks of 16 bytes
+
+__global__ __launch_bounds__(kBlock) void k_ipv4_validate(const uint8_t* __restrict__ hdrs, u32 n, u32 ext_tcp,
+                                                          u32* __restrict__ out) {
+    __shared__ u32x4 stage[kHdrChunksPerBlock];
+    const u32 h0 = blockIdx.x * kHdrPerBlock;
+    const u64 total_chunks = ((u64)n * 20u + 15u) >> 4;  // host guarantees the buffer is padded to 16 bytes
+    const u64 c0 = (u64)blockIdx.x * kHdrChunksPerBlock;
+    const u32x4* src = reinterpret_cast<const u32x4*>(hdrs);
+#pragma unroll
+    for (u32 q = 0; q < kHdrChunksPerBlock / kBlock; ++q) {
+        const u32 c = q * kBlock + threadIdx.x;
+        u32x4 v = {0, 0, 0, 0};
+        if (c0 + c < total_chunks) v = src[c0 + c];
+        stage[c] = v;
+    }
+    __syncthreads();
+    const u32* w = reinterpret_cast<const u32*>(stage);
+#pragma unroll
+    for (u32 q = 0; q < kHdrPerThread; ++q) {
+        const u32 h = q * kBlock + threadIdx.x;
+        if (h0 + h < n) {
+            const u32* r = w + h * 5u;
+            out[h0 + h] = ipv4_header_verdict(r[0], r[1], r[2], r[3], r[4], ext_tcp);
+        }
+    }
+}
+
+// ------------------------------- a7, a9, a10: transmit-side checksum fill, in place
+// status[i] = 0 when filled, else the reason the record was left alone.
+__global__ __launch_bounds__(kBlock) void k_generate(Batch b, uint8_t* __restrict__ arena_rw,
+                                                     uint8_t* __restrict__ status) {
+    Tile t;
+    if (!t.init(b)) return;
+    const u64 okmask = __ballot(t.my_ok);
+    u32 my_st = V_NONE;
+    for (u32 j = 0; j < t.cnt; ++j) {
+        const u32 flen = rdlane(t.my_len, j);
+        const u32 slot = rdlane(t.my_slot, j);
+        if (!((okmask >> j) & 1ull)) { if (t.lane == j) my_st = V_DROP_L3_TRUNCATED; continue; }
+        const u32x4* p = reinterpret_cast<const u32x4*>(b.arena + (u64)slot * 16u);
+        uint8_t* rec = arena_rw + (u64)slot * 16u;
+        const u32 nch = (flen + 15u) >> 4;
+        WaveFetch f;
+        f.r = u32x4{0, 0, 0, 0};
+        if (t.lane < nch) f.r = p[t.lane];
+        u32 st = 0;
+        if (flen < 20u) {
+            st = V_DROP_L3_TRUNCATED;
+        } else {
+            const u32 w0 = f(0), w1 = f(1), w2 = f(2), w3 = f(3), w4 = f(4);
+            const u32 proto = (w2 >> 8) & 0xffu;
+            const u32 vhl = w0 & 0xffu;
+            const u32 seglen = flen - 20u;
+            if (!(proto == 1u || proto == 17u)) st = V_DROP_L3_PROTO;
+            else if ((vhl >> 4) != 4u) st = V_DROP_L3_VERSION;
+            else if ((vhl & 0xfu) < 5u) st = V_DROP_L3_IHL_SHORT;
+            else if ((vhl & 0xfu) > 5u) st = V_DROP_L3_IHL_LONG;
+            else if (seglen < 8u) st = proto == 17u ? V_DROP_UDP_SHORT : V_DROP_ICMP_TRUNCATED;
+            else {
+                const u32 total = record_sum(p, flen, nch, f.r, t.lane);
+                // IPv4 header field zeroed, then summed (src/protocols/ipv4.rs:374-389)
+                const u32 hdr = halves(w0) + halves(w1) + (w2 & 0xffffu) + halves(w3) + halves(w4);
+                const u32 ipck = finish(hdr);
+                const u32 prefix = hdr + (w2 >> 16);
+                u32 l4ck, l4off;
+                if (proto == 17u) {
+                    // s = ck(pseudo, 0); c = ck(hdr(cksum 0) || payload, !s)  (src/transport/udp.rs:200-203)
+                    const u32 u1 = f(6);
+                    const u32 pseudo = halves(w3) + halves(w4) + 0x1100u + bswap16(seglen);
+                    l4ck = finish(total - prefix - (u1 >> 16) + pseudo);
+                    l4off = 26u;
+                } else {
+                    // ck(hdr(cksum 0) || data, 0)  (src/transport/icmp.rs:81-85)
+                    const u32 m0 = f(5);
+                    l4ck = finish(total - prefix - (m0 >> 16));
+                    l4off = 22u;
+                }
+                if (t.lane == 0u) {
+                    *reinterpret_cast<uint16_t*>(rec + 10) = (uint16_t)bswap16(ipck);
+                    *reinterpret_cast<uint16_t*>(rec + l4off) = (uint16_t)bswap16(l4ck);
+                }
+            }
+        }
+        if (t.lane == j) my_st = st;
+    }
+    if (status && t.lane < t.cnt) status[t.first + t.lane] = (uint8_t)my_st;
+}
+
+// ------------------------------------------------------------------ verdict histogram
+__global__ __launch_bounds__(kBlock) void k_count_verdicts(const u32* __restrict__ results, u32 n,
+                                                           unsigned long long* __restrict__ counts) {
+    __shared__ u32 hist[V_COUNT];
+    if (threadIdx.x < V_COUNT) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < n; i += (u64)gridDim.x * kBlock) {
+        const u32 v = (results[i] >> 16) & 0xffu;
+        atomicAdd(&hist[v < V_COUNT ? v : 0u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < V_COUNT && hist[threadIdx.x] != 0u) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------ flow hash
+__host__ __device__ inline u32 rotl32(u32 x, int r) { return (x << r) | (x >> (32 - r)); }
+// MurmurHash3 x86_32 over {src, dst, sport << 16 | dport, proto}, seed "unet".
+__host__ __device__ inline u32 flow_hash5(u32 src, u32 dst, u32 proto, u32 sport, u32 dport) {
+    const u32 w[4] = {src, dst, (sport << 16) | dport, proto};
+    u32 h = 0x756e6574u;
+    for (int i = 0; i < 4; i++) {
+        u32 k = w[i] * 0xcc9e2d51u;
+        k = rotl32(k, 15);
+        k *= 0x1b873593u;
+        h ^= k;
+        h = rotl32(h, 13);
+        h = h * 5u + 0xe6546b64u;
+    }
+    h ^= 16u;
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+
+// One lane per record; only the first few header bytes are touched.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_flow_hash(Batch b, u32* __restrict__ out) {
+    const u32 i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= b.n) return;
+    const u32 flen = b.len[i];
+    const u64 slot = b.off16 ? b.off16[i] : (u64)i * b.stride16;
+    const u64 end = slot * 16u + (((u64)flen + 15u) & ~15ull);
+    u32 h = 0;
+    if (flen <= kMaxLen && end <= b.arena_bytes) {
+        const u32* w = reinterpret_cast<const u32*>(b.arena + slot * 16u);
+        auto f = [w](u32 k) { return w[k]; };
+        u32 l3len = flen;
+        bool ok = true;
+        if (MODE == MODE_L2) {
+            ok = flen >= 14u && bswap16(w[3] & 0xffffu) == 0x0800u;
+            l3len = flen - 14u;
+        }
+        if (ok && l3len >= 20u) {
+            const u32 w0 = l3raw<MODE>(f, 0), w2 = l3raw<MODE>(f, 8);
+            const u32 src = bswap32(l3raw<MODE>(f, 12)), dst = bswap32(l3raw<MODE>(f, 16));
+            const u32 proto = (w2 >> 8) & 0xffu;
+            const u32 hl = (w0 & 0xfu) * 4u;
+            u32 sport = 0, dport = 0;
+            if ((proto == 17u || proto == 6u) && hl >= 20u && hl + 4u <= l3len) {
+                const u32 p0 = l3raw<MODE>(f, hl);
+                sport = bswap16(p0 & 0xffffu);
+                dport = bswap16(p0 >> 16);
+            }
+            h = flow_hash5(src, dst, proto, sport, dport);
+        }
+    }
+    out[i] = h;
+}
+
+// ------------------------------------------------------------------ bandwidth yardstick
+__global__ __launch_bounds__(kBlock) void k_stream_read(const u32x4* __restrict__ buf, u64 nchunks,
+                                                        u32* __restrict__ sink) {
+    u32 acc = 0;
+    const u64 stride = (u64)gridDim.x * kBlock;
+    u64 i = (u64)blockIdx.x * kBlock + threadIdx.x;
+    for (; i + 3 * stride < nchunks; i += 4 * stride) {
+        const u32x4 a = buf[i], b = buf[i + stride], c = buf[i + 2 * stride], d = buf[i + 3 * stride];
+        acc = sum_chunk(a, acc);
+        acc = sum_chunk(b, acc);
+        acc = sum_chunk(c, acc);
+        acc = sum_chunk(d, acc);
+    }
+    for (; i < nchunks; i += stride) acc = sum_chunk(buf[i], acc);
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63u) == 0u) atomicAdd(&sink[blockIdx.x & 4095u], acc);
+}
+
+// ------------------------------------------------------------------ synthetic traces
+// Layer 1 (+ the post-checksum payload flip): one wave per record, 16 bytes per lane.
+__global__ __launch_bounds__(kBlock) void k_synth_raw(int kind, u64 seed, u64 first_idx, u32 n,
+                                                      const u32* __restrict__ off16, u32 stride16,
+                                                      const u32* __restrict__ len, uint8_t* __restrict__ arena) {
+    const u32 lane = threadIdx.x & 63u;
+    const u32 rec = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (rec >= n) return;
+    const u64 idx = first_idx + rec;
+    const u64 key = unetsynth::key_of(seed, idx);
+    const unetsynth::Shape s = unetsynth::shape_of(kind, seed, idx);
+    const u32 flen = len[rec];
+    const u64 slot = off16 ? off16[rec] : (u64)rec * stride16;
+    u32 fpos = 0, fmask = 0;
+    const bool has_flip = unetsynth::flip_of(kind, key, s, &fpos, &fmask);
+    u64* dst = reinterpret_cast<u64*>(arena + slot * 16u);
+    const u32 nch = (flen + 15u) >> 4;
+    for (u32 c = lane; c < nch; c += kWave) {
+        u64 a = unetsynth::raw_word(key, 2u * c), b2 = unetsynth::raw_word(key, 2u * c + 1u);
+        if (has_flip && (fpos >> 4) == c) {
+            const u64 m = (u64)fmask << (8u * (fpos & 7u));
+            if (fpos & 8u) b2 ^= m; else a ^= m;
+        }
+        dst[2u * c] = a;
+        dst[2u * c + 1u] = b2;
+    }
+}
+
+// Layer 2: one lane per record builds the headers (with their checksums) and stores them.
+__global__ __launch_bounds__(kBlock) void k_synth_hdr(int kind, u64 seed, u64 first_idx, u32 n, u32 unicast,
+                                                      u32 broadcast, const u32* __restrict__ off16, u32 stride16,
+                                                      uint8_t* __restrict__ arena) {
+    const u32 rec = blockIdx.x * kBlock + threadIdx.x;
+    if (rec >= n) return;
+    const u64 idx = first_idx + rec;
+    const u64 key = unetsynth::key_of(seed, idx);
+    const unetsynth::Shape s = unetsynth::shape_of(kind, seed, idx);
+    uint8_t h[96];
+    const u32 hb = unetsynth::build_header(kind, key, s, unicast, broadcast, h);
+    uint8_t* base = kind == unetsynth::kKindHdr20 ? arena + (u64)rec * 20u
+                                                  : arena + (off16 ? (u64)off16[rec] : (u64)rec * stride16) * 16u;
+    u32* dst = reinterpret_cast<u32*>(base);
+    for (u32 i = 0; i < hb; i += 4) {
+        dst[i >> 2] = (u32)h[i] | ((u32)h[i + 1] << 8) | ((u32)h[i + 2] << 16) | ((u32)h[i + 3] << 24);
+    }
+}
+
+}  // namespace unetdev

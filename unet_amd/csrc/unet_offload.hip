@@ -1,0 +1,521 @@
+// C ABI of the offload (include/unet_offload.h): argument checking, launches, and the
+// host-pointer wrappers that stage batches through pinned memory.  No checksum or verdict is
+// ever computed on the host here.
+#include "../../include/unet_offload.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "kernels.h"
+
+using namespace unetdev;
+
+static_assert(sizeof(unet_result) == 4, "unet_result must stay 4 bytes");
+static_assert((int)UNET_V_COUNT == (int)V_COUNT, "verdict tables out of sync");
+static_assert((int)UNET_V_L3_HEADER_OK == (int)V_L3_HEADER_OK, "verdict tables out of sync");
+static_assert((int)UNET_V_ACCEPT_UDP == (int)V_ACCEPT_UDP, "verdict tables out of sync");
+static_assert((int)UNET_V_ACCEPT_TCP == (int)V_ACCEPT_TCP, "verdict tables out of sync");
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(UNET_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr size_t kStageBytes = 32u << 20;  // two pinned staging buffers of this size
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct unet_ctx {
+    int device = 0;
+    hipStream_t s_comp = nullptr;  // kernels (and D2H of results)
+    hipStream_t s_copy = nullptr;  // H2D staging
+    void* pinned[2] = {nullptr, nullptr};
+    hipEvent_t pinned_free[2] = {nullptr, nullptr};
+    hipEvent_t copied = nullptr;
+    DevBuf d_arena, d_off, d_len, d_out, d_aux;
+};
+
+namespace {
+
+int ensure(unet_ctx* c, DevBuf& b, size_t bytes) {
+    (void)c;
+    if (bytes <= b.cap) return UNET_OK;
+    if (b.p) HIP_TRY(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = (bytes + (1u << 20) - 1) & ~((size_t)(1u << 20) - 1);
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) return fail(UNET_E_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    b.cap = want;
+    return UNET_OK;
+}
+
+// Host -> device through the two pinned buffers, on the copy stream.
+int h2d(unet_ctx* c, void* dst, const void* src, size_t bytes) {
+    size_t off = 0;
+    int which = 0;
+    while (off < bytes) {
+        const size_t nb = bytes - off < kStageBytes ? bytes - off : kStageBytes;
+        HIP_TRY(hipEventSynchronize(c->pinned_free[which]));
+        memcpy(c->pinned[which], (const char*)src + off, nb);
+        HIP_TRY(hipMemcpyAsync((char*)dst + off, c->pinned[which], nb, hipMemcpyHostToDevice, c->s_copy));
+        HIP_TRY(hipEventRecord(c->pinned_free[which], c->s_copy));
+        off += nb;
+        which ^= 1;
+    }
+    return UNET_OK;
+}
+
+// Make the compute stream wait for everything queued on the copy stream so far.
+int copies_before_compute(unet_ctx* c) {
+    HIP_TRY(hipEventRecord(c->copied, c->s_copy));
+    HIP_TRY(hipStreamWaitEvent(c->s_comp, c->copied, 0));
+    return UNET_OK;
+}
+
+int d2h_sync(unet_ctx* c, void* dst, const void* src, size_t bytes) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->s_comp));
+    HIP_TRY(hipStreamSynchronize(c->s_comp));
+    return UNET_OK;
+}
+
+IfaceDev to_dev(const unet_iface* i) {
+    IfaceDev d;
+    d.unicast = i->unicast;
+    d.broadcast = i->broadcast;
+    d.mac_lo = (u32)i->mac[0] | ((u32)i->mac[1] << 8) | ((u32)i->mac[2] << 16) | ((u32)i->mac[3] << 24);
+    d.mac_hi = (u32)i->mac[4] | ((u32)i->mac[5] << 8);
+    d.ext_tcp = i->ext_tcp ? 1u : 0u;
+    return d;
+}
+
+int check_batch(unet_ctx* ctx, const void* arena, const void* off16, u32 stride16, const void* len, u32 n) {
+    if (!ctx) return fail(UNET_E_INVAL, "null context");
+    if (n == 0) return UNET_OK;
+    if (!arena || !len) return fail(UNET_E_INVAL, "null arena or length table");
+    if (((uintptr_t)arena & 15u) != 0) return fail(UNET_E_INVAL, "arena must be 16-byte aligned");
+    if (!off16 && stride16 == 0) return fail(UNET_E_INVAL, "need an offset table or a non-zero stride");
+    return UNET_OK;
+}
+
+inline hipStream_t pick(unet_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->s_comp; }
+inline u32 tiles_grid(u32 n) {
+    const u32 tiles = (n + kTile - 1) / kTile;
+    return (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
+}
+
+// Shared body of the host-pointer batch calls: upload arena + tables, leave device views in `b`.
+int upload_batch(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16, uint32_t stride16,
+                 const uint32_t* len, uint32_t n, Batch* b) {
+    // every record (plus its pad to 16 bytes) must lie inside the caller's arena
+    for (u32 i = 0; i < n; i++) {
+        if (len[i] > kMaxLen) return fail(UNET_E_RANGE, "record %u: length %u > 65535", i, len[i]);
+        const u64 slot = off16 ? off16[i] : (u64)i * stride16;
+        const u64 end = slot * 16u + (((u64)len[i] + 15u) & ~15ull);
+        if (end > arena_bytes) return fail(UNET_E_RANGE, "record %u ends at byte %llu, arena is %llu bytes (records are read in 16-byte chunks)", i, (unsigned long long)end, (unsigned long long)arena_bytes);
+    }
+    int rc;
+    if ((rc = ensure(c, c->d_arena, arena_bytes))) return rc;
+    if ((rc = ensure(c, c->d_len, (size_t)n * 4))) return rc;
+    if (off16 && (rc = ensure(c, c->d_off, (size_t)n * 4))) return rc;
+    if ((rc = h2d(c, c->d_len.p, len, (size_t)n * 4))) return rc;
+    if (off16 && (rc = h2d(c, c->d_off.p, off16, (size_t)n * 4))) return rc;
+    if ((rc = h2d(c, c->d_arena.p, arena, arena_bytes))) return rc;
+    if ((rc = copies_before_compute(c))) return rc;
+    b->arena = (const uint8_t*)c->d_arena.p;
+    b->arena_bytes = arena_bytes;
+    b->off16 = off16 ? (const u32*)c->d_off.p : nullptr;
+    b->stride16 = stride16;
+    b->len = (const u32*)c->d_len.p;
+    b->n = n;
+    return UNET_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* unet_last_error(void) { return g_err; }
+
+int unet_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int unet_open(int device_id, unet_ctx** out_ctx) {
+    if (!out_ctx) return fail(UNET_E_INVAL, "null out_ctx");
+    *out_ctx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(UNET_E_NODEV, "no HIP device visible");
+    if (device_id < 0 || device_id >= n) return fail(UNET_E_NODEV, "device %d out of range (0..%d)", device_id, n - 1);
+    HIP_TRY(hipSetDevice(device_id));
+    unet_ctx* c = new (std::nothrow) unet_ctx();
+    if (!c) return fail(UNET_E_NOMEM, "out of host memory");
+    c->device = device_id;
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_comp, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipHostMalloc(&c->pinned[i], kStageBytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->pinned_free[i], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->copied, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        fail(UNET_E_HIP, "context setup failed: %s", hipGetErrorString(e));
+        unet_close(c);
+        return UNET_E_HIP;
+    }
+    *out_ctx = c;
+    return UNET_OK;
+}
+
+void unet_close(unet_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->s_comp) (void)hipStreamSynchronize(c->s_comp);
+    if (c->s_copy) (void)hipStreamSynchronize(c->s_copy);
+    DevBuf* bufs[] = {&c->d_arena, &c->d_off, &c->d_len, &c->d_out, &c->d_aux};
+    for (DevBuf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (int i = 0; i < 2; i++) {
+        if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
+        if (c->pinned_free[i]) (void)hipEventDestroy(c->pinned_free[i]);
+    }
+    if (c->copied) (void)hipEventDestroy(c->copied);
+    if (c->s_comp) (void)hipStreamDestroy(c->s_comp);
+    if (c->s_copy) (void)hipStreamDestroy(c->s_copy);
+    delete c;
+}
+
+int unet_sync(unet_ctx* c) {
+    if (!c) return fail(UNET_E_INVAL, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->s_copy));
+    HIP_TRY(hipStreamSynchronize(c->s_comp));
+    return UNET_OK;
+}
+
+/* ---------------------------------------------------------------- a1 */
+
+int unet_csum_batch_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_t arena_bytes,
+                        const uint32_t* d_off16, uint32_t stride16, const uint32_t* d_len,
+                        const uint16_t* d_seeds, uint32_t n, uint16_t* d_out) {
+    int rc = check_batch(ctx, d_arena, d_off16, stride16, d_len, n);
+    if (rc) return rc;
+    if (n == 0) return UNET_OK;
+    if (!d_out) return fail(UNET_E_INVAL, "null output");
+    HIP_TRY(hipSetDevice(ctx->device));
+    Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
+    hipLaunchKernelGGL(k_csum, dim3(tiles_grid(n)), dim3(kBlock), 0, pick(ctx, stream), b, d_seeds, d_out);
+    HIP_TRY(hipGetLastError());
+    return UNET_OK;
+}
+
+int unet_csum_batch(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16,
+                    uint32_t stride16, const uint32_t* len, const uint16_t* seeds, uint32_t n, uint16_t* out) {
+    if (!c) return fail(UNET_E_INVAL, "null context");
+    if (n == 0) return UNET_OK;
+    if (!arena || !len || !out) return fail(UNET_E_INVAL, "null argument");
+    if (!off16 && stride16 == 0) return fail(UNET_E_INVAL, "need an offset table or a non-zero stride");
+    HIP_TRY(hipSetDevice(c->device));
+    Batch b;
+    int rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b);
+    if (rc) return rc;
+    if ((rc = ensure(c, c->d_out, (size_t)n * 2))) return rc;
+    const uint16_t* d_seeds = nullptr;
+    if (seeds) {
+        if ((rc = ensure(c, c->d_aux, (size_t)n * 2))) return rc;
+        if ((rc = h2d(c, c->d_aux.p, seeds, (size_t)n * 2))) return rc;
+        if ((rc = copies_before_compute(c))) return rc;
+        d_seeds = (const uint16_t*)c->d_aux.p;
+    }
+    rc = unet_csum_batch_dev(c, nullptr, b.arena, b.arena_bytes, b.off16, b.stride16, b.len, d_seeds, n,
+                             (uint16_t*)c->d_out.p);
+    if (rc) return rc;
+    return d2h_sync(c, out, c->d_out.p, (size_t)n * 2);
+}
+
+int unet_csum(unet_ctx* c, const uint8_t* data, size_t len, uint16_t seed, uint16_t* out) {
+    if (!c || !out || (!data && len)) return fail(UNET_E_INVAL, "null argument");
+    if (len > kMaxLen) return fail(UNET_E_RANGE, "length %zu > 65535", len);
+    HIP_TRY(hipSetDevice(c->device));
+    // one record, padded to a whole number of 16-byte chunks inside the pinned buffer
+    const size_t padded = (len + 15) & ~(size_t)15;
+    int rc;
+    if ((rc = ensure(c, c->d_arena, padded + 16))) return rc;
+    if ((rc = ensure(c, c->d_len, 16))) return rc;
+    if ((rc = ensure(c, c->d_out, 16))) return rc;
+    HIP_TRY(hipEventSynchronize(c->pinned_free[0]));
+    uint8_t* pin = (uint8_t*)c->pinned[0];
+    memset(pin, 0, padded + 32);
+    memcpy(pin, data, len);
+    u32 l32 = (u32)len;
+    memcpy(pin + padded, &l32, 4);
+    memcpy(pin + padded + 4, &seed, 2);
+    HIP_TRY(hipMemcpyAsync(c->d_arena.p, pin, padded ? padded : 16, hipMemcpyHostToDevice, c->s_comp));
+    HIP_TRY(hipMemcpyAsync(c->d_len.p, pin + padded, 8, hipMemcpyHostToDevice, c->s_comp));
+    HIP_TRY(hipEventRecord(c->pinned_free[0], c->s_comp));
+    rc = unet_csum_batch_dev(c, nullptr, (const uint8_t*)c->d_arena.p, padded, nullptr, 1, (const u32*)c->d_len.p,
+                             (const uint16_t*)((const uint8_t*)c->d_len.p + 4), 1, (uint16_t*)c->d_out.p);
+    if (rc) return rc;
+    return d2h_sync(c, out, c->d_out.p, 2);
+}
+
+/* ---------------------------------------------------------------- a2-a4 */
+
+int unet_ipv4_validate_dev(unet_ctx* ctx, void* stream, const uint8_t* d_hdrs, uint32_t n, const unet_iface* iface,
+                           unet_result* d_out) {
+    if (!ctx) return fail(UNET_E_INVAL, "null context");
+    if (n == 0) return UNET_OK;
+    if (!d_hdrs || !iface || !d_out) return fail(UNET_E_INVAL, "null argument");
+    if (((uintptr_t)d_hdrs & 15u) != 0) return fail(UNET_E_INVAL, "header buffer must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const u32 grid = (n + kHdrPerBlock - 1) / kHdrPerBlock;
+    hipLaunchKernelGGL(k_ipv4_validate, dim3(grid), dim3(kBlock), 0, pick(ctx, stream), d_hdrs, n,
+                       (u32)(iface->ext_tcp ? 1 : 0), (u32*)d_out);
+    HIP_TRY(hipGetLastError());
+    return UNET_OK;
+}
+
+int unet_ipv4_validate(unet_ctx* c, const uint8_t* hdrs, uint32_t n, const unet_iface* iface, unet_result* out) {
+    if (!c) return fail(UNET_E_INVAL, "null context");
+    if (n == 0) return UNET_OK;
+    if (!hdrs || !iface || !out) return fail(UNET_E_INVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t)n * 20;
+    int rc;
+    if ((rc = ensure(c, c->d_arena, bytes + 16))) return rc;  // device buffer covers the last partial chunk
+    if ((rc = ensure(c, c->d_out, (size_t)n * 4))) return rc;
+    if ((rc = h2d(c, c->d_arena.p, hdrs, bytes))) return rc;
+    if ((rc = copies_before_compute(c))) return rc;
+    if ((rc = unet_ipv4_validate_dev(c, nullptr, (const uint8_t*)c->d_arena.p, n, iface, (unet_result*)c->d_out.p))) return rc;
+    return d2h_sync(c, out, c->d_out.p, (size_t)n * 4);
+}
+
+/* ---------------------------------------------------------------- receive path */
+
+int unet_verify_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_t arena_bytes,
+                    const uint32_t* d_off16, uint32_t stride16, const uint32_t* d_len, uint32_t n,
+                    const unet_iface* iface, unet_result* d_out) {
+    int rc = check_batch(ctx, d_arena, d_off16, stride16, d_len, n);
+    if (rc) return rc;
+    if (n == 0) return UNET_OK;
+    if (!iface || !d_out) return fail(UNET_E_INVAL, "null iface or output");
+    if (iface->mode != UNET_MODE_L3 && iface->mode != UNET_MODE_L2) return fail(UNET_E_INVAL, "bad iface mode %d", iface->mode);
+    HIP_TRY(hipSetDevice(ctx->device));
+    Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
+    const IfaceDev ifc = to_dev(iface);
+    if (iface->mode == UNET_MODE_L2)
+        hipLaunchKernelGGL(k_verify<MODE_L2>, dim3(tiles_grid(n)), dim3(kBlock), 0, pick(ctx, stream), b, ifc, (u32*)d_out);
+    else
+        hipLaunchKernelGGL(k_verify<MODE_L3>, dim3(tiles_grid(n)), dim3(kBlock), 0, pick(ctx, stream), b, ifc, (u32*)d_out);
+    HIP_TRY(hipGetLastError());
+    return UNET_OK;
+}
+
+int unet_verify(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16, uint32_t stride16,
+                const uint32_t* len, uint32_t n, const unet_iface* iface, unet_result* out) {
+    if (!c) return fail(UNET_E_INVAL, "null context");
+    if (n == 0) return UNET_OK;
+    if (!arena || !len || !iface || !out) return fail(UNET_E_INVAL, "null argument");
+    if (!off16 && stride16 == 0) return fail(UNET_E_INVAL, "need an offset table or a non-zero stride");
+    HIP_TRY(hipSetDevice(c->device));
+    Batch b;
+    int rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b);
+    if (rc) return rc;
+    if ((rc = ensure(c, c->d_out, (size_t)n * 4))) return rc;
+    rc = unet_verify_dev(c, nullptr, b.arena, b.arena_bytes, b.off16, b.stride16, b.len, n, iface, (unet_result*)c->d_out.p);
+    if (rc) return rc;
+    return d2h_sync(c, out, c->d_out.p, (size_t)n * 4);
+}
+
+/* ---------------------------------------------------------------- transmit path */
+
+int unet_generate_dev(unet_ctx* ctx, void* stream, uint8_t* d_arena, uint64_t arena_bytes, const uint32_t* d_off16,
+                      uint32_t stride16, const uint32_t* d_len, uint32_t n, uint8_t* d_status) {
+    int rc = check_batch(ctx, d_arena, d_off16, stride16, d_len, n);
+    if (rc) return rc;
+    if (n == 0) return UNET_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
+    hipLaunchKernelGGL(k_generate, dim3(tiles_grid(n)), dim3(kBlock), 0, pick(ctx, stream), b, d_arena, d_status);
+    HIP_TRY(hipGetLastError());
+    return UNET_OK;
+}
+
+int unet_generate(unet_ctx* c, uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16, uint32_t stride16,
+                  const uint32_t* len, uint32_t n, uint8_t* status) {
+    if (!c) return fail(UNET_E_INVAL, "null context");
+    if (n == 0) return UNET_OK;
+    if (!arena || !len) return fail(UNET_E_INVAL, "null argument");
+    if (!off16 && stride16 == 0) return fail(UNET_E_INVAL, "need an offset table or a non-zero stride");
+    HIP_TRY(hipSetDevice(c->device));
+    Batch b;
+    int rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b);
+    if (rc) return rc;
+    if ((rc = ensure(c, c->d_out, (size_t)n))) return rc;
+    rc = unet_generate_dev(c, nullptr, (uint8_t*)c->d_arena.p, arena_bytes, b.off16, b.stride16, b.len, n, (uint8_t*)c->d_out.p);
+    if (rc) return rc;
+    if (status && (rc = d2h_sync(c, status, c->d_out.p, (size_t)n))) return rc;
+    return d2h_sync(c, arena, c->d_arena.p, arena_bytes);
+}
+
+/* ---------------------------------------------------------------- counters */
+
+int unet_count_verdicts_dev(unet_ctx* ctx, void* stream, const unet_result* d_results, uint32_t n, uint64_t* d_counts) {
+    if (!ctx) return fail(UNET_E_INVAL, "null context");
+    if (n == 0) return UNET_OK;
+    if (!d_results || !d_counts) return fail(UNET_E_INVAL, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    u32 grid = (n + kBlock - 1) / kBlock;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_count_verdicts, dim3(grid), dim3(kBlock), 0, pick(ctx, stream), (const u32*)d_results, n,
+                       (unsigned long long*)d_counts);
+    HIP_TRY(hipGetLastError());
+    return UNET_OK;
+}
+
+/* ---------------------------------------------------------------- flow hash */
+
+uint32_t unet_flow_hash5(uint32_t src, uint32_t dst, uint8_t proto, uint16_t sport, uint16_t dport) {
+    return flow_hash5(src, dst, proto, sport, dport);
+}
+
+int unet_flow_hash_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_t arena_bytes,
+                       const uint32_t* d_off16, uint32_t stride16, const uint32_t* d_len, uint32_t n,
+                       const unet_iface* iface, uint32_t* d_hash) {
+    int rc = check_batch(ctx, d_arena, d_off16, stride16, d_len, n);
+    if (rc) return rc;
+    if (n == 0) return UNET_OK;
+    if (!iface || !d_hash) return fail(UNET_E_INVAL, "null iface or output");
+    HIP_TRY(hipSetDevice(ctx->device));
+    Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
+    const u32 grid = (n + kBlock - 1) / kBlock;
+    if (iface->mode == UNET_MODE_L2)
+        hipLaunchKernelGGL(k_flow_hash<MODE_L2>, dim3(grid), dim3(kBlock), 0, pick(ctx, stream), b, d_hash);
+    else
+        hipLaunchKernelGGL(k_flow_hash<MODE_L3>, dim3(grid), dim3(kBlock), 0, pick(ctx, stream), b, d_hash);
+    HIP_TRY(hipGetLastError());
+    return UNET_OK;
+}
+
+/* ---------------------------------------------------------------- synthetic traces */
+
+static bool kind_ok(int kind) {
+    return kind == UNET_SYNTH_IPV4_HDR20 || kind == UNET_SYNTH_UDP1500 || kind == UNET_SYNTH_IMIX;
+}
+
+uint32_t unet_synth_len(int kind, uint64_t seed, uint64_t idx) {
+    if (!kind_ok(kind)) return 0;
+    return unetsynth::shape_of(kind, seed, idx).len;
+}
+
+int unet_synth_layout(int kind, uint64_t seed, uint64_t first_idx, uint32_t n, uint32_t* off16, uint32_t* len,
+                      uint64_t* arena_bytes) {
+    if (!kind_ok(kind)) return fail(UNET_E_INVAL, "unknown trace kind %d", kind);
+    u64 slot = 0;
+    for (u32 i = 0; i < n; i++) {
+        const u32 l = unetsynth::shape_of(kind, seed, first_idx + i).len;
+        if (len) len[i] = l;
+        if (kind == UNET_SYNTH_IPV4_HDR20) {
+            if (off16) off16[i] = 0;  // stride 20: not addressable in 16-byte slots
+            continue;
+        }
+        if (slot > 0xffffffffull) return fail(UNET_E_RANGE, "trace does not fit 2^32 slots");
+        if (off16) off16[i] = (u32)slot;
+        slot += (l + 15u) >> 4;
+    }
+    if (arena_bytes) *arena_bytes = kind == UNET_SYNTH_IPV4_HDR20 ? (((u64)n * 20u + 15u) & ~15ull) : slot * 16u;
+    return UNET_OK;
+}
+
+int unet_synth_host(int kind, uint64_t seed, uint64_t first_idx, uint32_t n, const unet_iface* iface,
+                    const uint32_t* off16, const uint32_t* len, uint8_t* arena, uint64_t arena_bytes) {
+    if (!kind_ok(kind)) return fail(UNET_E_INVAL, "unknown trace kind %d", kind);
+    if (!iface || !arena) return fail(UNET_E_INVAL, "null argument");
+    if (kind != UNET_SYNTH_IPV4_HDR20 && !off16) return fail(UNET_E_INVAL, "offset table required");
+    (void)len;
+    for (u32 r = 0; r < n; r++) {
+        const u64 idx = first_idx + r;
+        const u64 key = unetsynth::key_of(seed, idx);
+        const unetsynth::Shape s = unetsynth::shape_of(kind, seed, idx);
+        uint8_t h[96];
+        if (kind == UNET_SYNTH_IPV4_HDR20) {
+            if ((u64)r * 20u + 20u > arena_bytes) return fail(UNET_E_RANGE, "arena too small");
+            unetsynth::build_header(kind, key, s, iface->unicast, iface->broadcast, h);
+            memcpy(arena + (u64)r * 20u, h, 20);
+            continue;
+        }
+        const u64 base = (u64)off16[r] * 16u;
+        const u32 padded = (s.len + 15u) & ~15u;
+        if (base + padded > arena_bytes) return fail(UNET_E_RANGE, "arena too small");
+        uint8_t* rec = arena + base;
+        for (u32 k = 0; k < padded / 8; k++) {
+            const u64 w = unetsynth::raw_word(key, k);
+            memcpy(rec + 8u * k, &w, 8);  // little-endian host
+        }
+        const u32 hb = unetsynth::build_header(kind, key, s, iface->unicast, iface->broadcast, h);
+        memcpy(rec, h, hb);
+        u32 fpos, fmask;
+        if (unetsynth::flip_of(kind, key, s, &fpos, &fmask)) rec[fpos] ^= (uint8_t)fmask;
+    }
+    return UNET_OK;
+}
+
+int unet_synth_dev(unet_ctx* ctx, void* stream, int kind, uint64_t seed, uint64_t first_idx, uint32_t n,
+                   const unet_iface* iface, const uint32_t* d_off16, const uint32_t* d_len, uint8_t* d_arena,
+                   uint64_t arena_bytes) {
+    if (!ctx) return fail(UNET_E_INVAL, "null context");
+    if (!kind_ok(kind)) return fail(UNET_E_INVAL, "unknown trace kind %d", kind);
+    if (n == 0) return UNET_OK;
+    if (!iface || !d_arena) return fail(UNET_E_INVAL, "null argument");
+    if (kind != UNET_SYNTH_IPV4_HDR20 && (!d_off16 || !d_len)) return fail(UNET_E_INVAL, "offset and length tables required");
+    if (kind == UNET_SYNTH_IPV4_HDR20 && (u64)n * 20u > arena_bytes) return fail(UNET_E_RANGE, "arena too small");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = pick(ctx, stream);
+    if (kind != UNET_SYNTH_IPV4_HDR20) {
+        const u32 grid = (n + (kBlock / kWave) - 1) / (kBlock / kWave);
+        hipLaunchKernelGGL(k_synth_raw, dim3(grid), dim3(kBlock), 0, s, kind, seed, first_idx, n, d_off16, 0u, d_len, d_arena);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_synth_hdr, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, kind, seed, first_idx, n,
+                       iface->unicast, iface->broadcast, d_off16, 0u, d_arena);
+    HIP_TRY(hipGetLastError());
+    return UNET_OK;
+}
+
+/* ---------------------------------------------------------------- yardstick */
+
+int unet_stream_read_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t bytes, uint32_t* d_sink) {
+    if (!ctx || !d_buf || !d_sink) return fail(UNET_E_INVAL, "null argument");
+    if (((uintptr_t)d_buf & 15u) != 0) return fail(UNET_E_INVAL, "buffer must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_stream_read, dim3(4096), dim3(kBlock), 0, pick(ctx, stream), (const u32x4*)d_buf, bytes / 16, d_sink);
+    HIP_TRY(hipGetLastError());
+    return UNET_OK;
+}
+
+}  // extern "C"
