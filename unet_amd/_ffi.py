@@ -137,6 +137,13 @@ def load_library(path: Optional[str] = None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7.  A process must hold ONE HIP runtime: if
+    # torch is going to be used beside this library (device buffers, torch.distributed), its runtime has
+    # to be the one already mapped when ours is dlopen'ed, so that the loader resolves our DT_NEEDED to it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(p):
         raise FileNotFoundError(
             f"{p} not found: build it with `python __graft_entry__.py build` (hipcc --offload-arch=gfx950); "
