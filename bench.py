@@ -89,7 +89,12 @@ def main():
     ext_tcp = (args.workload == "imix") if args.ext_tcp is None else bool(args.ext_tcp)
     ifc = unet_amd.Iface(ext_tcp=ext_tcp)
     ctx = unet_amd.Offload(local)
-    stream = torch.cuda.current_stream().cuda_stream
+    # A dedicated torch stream: its raw handle goes to the C ABI, so the kernels, torch's own ops and the
+    # HIP events used for timing (torch.cuda.Event records on the current stream) share one queue.
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream, "need a non-null stream handle (NULL selects the library's private stream)"
     first_idx = rank * n
 
     # ---- build the batch in HBM

@@ -27,8 +27,18 @@ def dev(a: np.ndarray):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+_STREAM = None
+
+
 def stream():
-    return torch_mod().cuda.current_stream().cuda_stream
+    """Raw handle of a dedicated torch stream.  Everything torch queued so far (fills, copies on its
+    default stream) is drained first, so the library's kernels never race with them."""
+    global _STREAM
+    torch = torch_mod()
+    if _STREAM is None:
+        _STREAM = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    return _STREAM.cuda_stream
 
 
 def results_to_numpy(t):
