@@ -58,10 +58,9 @@ struct TailMask {
 
 // Exact byte-swapped-word sum of record [0, flen) given row 0 already loaded; wave-uniform result.
 // `p` points at the record, `nch` = ceil(flen / 16).
-__device__ __forceinline__ u32 record_sum(const u32x4* __restrict__ p, u32 flen, u32 nch, u32x4 row0, u32 lane) {
-    const TailMask tm(flen, nch);
-    u32 acc = sum_chunk(tm.apply(row0, lane), 0u);
-    for (u32 c0 = kWave; c0 < nch; c0 += 4u * kWave) {
+// Rows from chunk `from` on, four 1 KiB loads in flight per iteration; per-lane partial sums.
+__device__ __forceinline__ u32 rows_sum(const u32x4* __restrict__ p, u32 nch, u32 from, const TailMask& tm, u32 lane, u32 acc) {
+    for (u32 c0 = from; c0 < nch; c0 += 4u * kWave) {
         const u32 i0 = c0 + lane, i1 = i0 + kWave, i2 = i1 + kWave, i3 = i2 + kWave;
         u32x4 a = {0, 0, 0, 0}, b = a, c = a, d = a;
         if (i0 < nch) a = p[i0];
@@ -73,7 +72,13 @@ __device__ __forceinline__ u32 record_sum(const u32x4* __restrict__ p, u32 flen,
         acc = sum_chunk(tm.apply(c, i2), acc);
         acc = sum_chunk(tm.apply(d, i3), acc);
     }
-    return wave_sum(acc);
+    return acc;
+}
+
+__device__ __forceinline__ u32 record_sum(const u32x4* __restrict__ p, u32 flen, u32 nch, u32x4 row0, u32 lane) {
+    const TailMask tm(flen, nch);
+    const u32 acc = sum_chunk(tm.apply(row0, lane), 0u);
+    return wave_sum(rows_sum(p, nch, kWave, tm, lane, acc));
 }
 
 // Tile bookkeeping shared by the wave-per-record kernels.
@@ -81,12 +86,13 @@ struct Tile {
     u32 first, cnt, lane;
     u32 my_len, my_slot;
     bool my_ok;
+    template <int TILE = (int)kTile>
     __device__ __forceinline__ bool init(const Batch& b) {
         lane = threadIdx.x & 63u;
         const u32 wave = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-        first = wave * kTile;
+        first = wave * (u32)TILE;
         if (first >= b.n) return false;
-        cnt = min(kTile, b.n - first);
+        cnt = min((u32)TILE, b.n - first);
         my_len = 0;
         my_slot = 0;
         my_ok = false;
@@ -132,28 +138,79 @@ __global__ __launch_bounds__(kBlock) void k_csum(Batch b, const uint16_t* __rest
 }
 
 // ------------------------------------------- a2-a6, a8, a11: receive-path verdicts
+// Rows 0 and 1 (the first 2 KiB) of one record, as loaded by a whole wave.
+struct Rows2 {
+    u32x4 r0, r1;
+    const u32x4* p;
+    u32 flen, nch;
+    bool ok;
+};
+
+// Issue (not wait for) the loads of record j of the tile.  Exactly two load instructions are issued
+// whatever the record's length -- lanes past the end re-read the record's last chunk (same address,
+// no extra HBM traffic) and are zeroed afterwards -- so the compiler can retire them with counted
+// waits (vmcnt(2)) while the next record's pair is still in flight.  `live` = false issues the same
+// two loads on one dummy chunk and marks the buffer unused.
+template <int TILE>
+__device__ __forceinline__ Rows2 issue_rows(const Batch& b, const Tile& t, u64 okmask, u32 j, bool live) {
+    Rows2 x;
+    x.flen = rdlane(t.my_len, j);
+    const u32 slot = rdlane(t.my_slot, j);
+    x.ok = live && ((okmask >> j) & 1ull) != 0ull;
+    x.nch = x.ok ? (x.flen + 15u) >> 4 : 0u;
+    x.p = reinterpret_cast<const u32x4*>(b.arena + (x.ok ? (u64)slot * 16u : 0ull));
+    const u32 last = x.nch != 0u ? x.nch - 1u : 0u;
+    const u32 i0 = t.lane, i1 = t.lane + kWave;
+    x.r0 = x.p[min(i0, last)];
+    x.r1 = x.p[min(i1, last)];
+    return x;
+}
+
+// Zero the lanes of a freshly loaded row that lie past the record's end.
+__device__ __forceinline__ u32x4 clip_row(u32x4 v, u32 chunk, u32 nch) {
+    const bool in = chunk < nch;
+    v.x = in ? v.x : 0u;
+    v.y = in ? v.y : 0u;
+    v.z = in ? v.z : 0u;
+    v.w = in ? v.w : 0u;
+    return v;
+}
+
+// Parse + sum + verdict of one record whose first two rows are in registers.
 template <int MODE>
+__device__ __forceinline__ u32 verify_one(const Rows2& cur, const IfaceDev& ifc, u32 lane) {
+    WaveFetch f;
+    f.r = cur.r0;
+    const Parsed P = parse_record<MODE>(f, cur.flen, ifc);
+    if (P.kind == K_DONE) return P.res;  // wave-uniform: records dropped on their headers are not summed
+    const TailMask tm(cur.flen, cur.nch);
+    u32 acc = sum_chunk(tm.apply(clip_row(cur.r0, lane, cur.nch), lane), 0u);
+    acc = sum_chunk(tm.apply(clip_row(cur.r1, lane + kWave, cur.nch), lane + kWave), acc);
+    acc = rows_sum(cur.p, cur.nch, 2u * kWave, tm, lane, acc);
+    return finalize_record(P, wave_sum(acc));
+}
+
+// One wave walks TILE consecutive records with two register buffers used alternately (no register
+// copies, so nothing forces an early wait): the loads of record j+1 are in flight while record j is
+// parsed (scalar unit, from lanes 0..5 of row 0) and summed.
+template <int MODE, int TILE>
 __global__ __launch_bounds__(kBlock) void k_verify(Batch b, IfaceDev ifc, u32* __restrict__ out) {
     Tile t;
-    if (!t.init(b)) return;
+    if (!t.init<TILE>(b)) return;
     const u64 okmask = __ballot(t.my_ok);
     u32 my_res = 0;  // V_NONE for records whose length/offset is out of range
-    for (u32 j = 0; j < t.cnt; ++j) {
-        const u32 flen = rdlane(t.my_len, j);
-        const u32 slot = rdlane(t.my_slot, j);
-        if (!((okmask >> j) & 1ull)) continue;
-        const u32x4* p = reinterpret_cast<const u32x4*>(b.arena + (u64)slot * 16u);
-        const u32 nch = (flen + 15u) >> 4;
-        WaveFetch f;
-        f.r = u32x4{0, 0, 0, 0};
-        if (t.lane < nch) f.r = p[t.lane];
-        const Parsed P = parse_record<MODE>(f, flen, ifc);
-        u32 res = P.res;
-        if (P.kind != K_DONE) {  // wave-uniform: records dropped on their headers are not summed
-            const u32 total = record_sum(p, flen, nch, f.r, t.lane);
-            res = finalize_record(P, total);
+    Rows2 A = issue_rows<TILE>(b, t, okmask, 0, true), B;
+    for (u32 j = 0; j < t.cnt; j += 2) {
+        B = issue_rows<TILE>(b, t, okmask, min(j + 1, t.cnt - 1), j + 1 < t.cnt);
+        if (A.ok) {
+            const u32 res = verify_one<MODE>(A, ifc, t.lane);
+            if (t.lane == j) my_res = res;
         }
-        if (t.lane == j) my_res = res;
+        A = issue_rows<TILE>(b, t, okmask, min(j + 2, t.cnt - 1), j + 2 < t.cnt);
+        if (B.ok) {
+            const u32 res = verify_one<MODE>(B, ifc, t.lane);
+            if (t.lane == j + 1) my_res = res;
+        }
     }
     if (t.lane < t.cnt) out[t.first + t.lane] = my_res;
 }

@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -119,10 +120,12 @@ int check_batch(unet_ctx* ctx, const void* arena, const void* off16, u32 stride1
     if (!off16 && stride16 == 0) return fail(UNET_E_INVAL, "need an offset table or a non-zero stride");
     return UNET_OK;
 }
+// the kernels may touch the arena's first 16 bytes even when every record is empty
+inline bool arena_too_small(u64 arena_bytes) { return arena_bytes < 16; }
 
 inline hipStream_t pick(unet_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->s_comp; }
-inline u32 tiles_grid(u32 n) {
-    const u32 tiles = (n + kTile - 1) / kTile;
+inline u32 tiles_grid(u32 n, u32 tile = kTile) {
+    const u32 tiles = (n + tile - 1) / tile;
     return (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
 }
 
@@ -324,14 +327,25 @@ int unet_verify_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_
     if (rc) return rc;
     if (n == 0) return UNET_OK;
     if (!iface || !d_out) return fail(UNET_E_INVAL, "null iface or output");
+    if (arena_too_small(arena_bytes)) return fail(UNET_E_INVAL, "arena must hold at least 16 bytes");
     if (iface->mode != UNET_MODE_L3 && iface->mode != UNET_MODE_L2) return fail(UNET_E_INVAL, "bad iface mode %d", iface->mode);
     HIP_TRY(hipSetDevice(ctx->device));
     Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
     const IfaceDev ifc = to_dev(iface);
-    if (iface->mode == UNET_MODE_L2)
-        hipLaunchKernelGGL(k_verify<MODE_L2>, dim3(tiles_grid(n)), dim3(kBlock), 0, pick(ctx, stream), b, ifc, (u32*)d_out);
-    else
-        hipLaunchKernelGGL(k_verify<MODE_L3>, dim3(tiles_grid(n)), dim3(kBlock), 0, pick(ctx, stream), b, ifc, (u32*)d_out);
+    constexpr int kVerifyTile = 16;
+    const int tile_env = getenv("UNET_VERIFY_TILE") ? atoi(getenv("UNET_VERIFY_TILE")) : kVerifyTile;
+    hipStream_t s = pick(ctx, stream);
+    if (iface->mode == UNET_MODE_L2) {
+        hipLaunchKernelGGL((k_verify<MODE_L2, kVerifyTile>), dim3(tiles_grid(n, kVerifyTile)), dim3(kBlock), 0, s, b, ifc, (u32*)d_out);
+    } else if (tile_env == 64) {
+        hipLaunchKernelGGL((k_verify<MODE_L3, 64>), dim3(tiles_grid(n, 64)), dim3(kBlock), 0, s, b, ifc, (u32*)d_out);
+    } else if (tile_env == 32) {
+        hipLaunchKernelGGL((k_verify<MODE_L3, 32>), dim3(tiles_grid(n, 32)), dim3(kBlock), 0, s, b, ifc, (u32*)d_out);
+    } else if (tile_env == 8) {
+        hipLaunchKernelGGL((k_verify<MODE_L3, 8>), dim3(tiles_grid(n, 8)), dim3(kBlock), 0, s, b, ifc, (u32*)d_out);
+    } else {
+        hipLaunchKernelGGL((k_verify<MODE_L3, kVerifyTile>), dim3(tiles_grid(n, kVerifyTile)), dim3(kBlock), 0, s, b, ifc, (u32*)d_out);
+    }
     HIP_TRY(hipGetLastError());
     return UNET_OK;
 }
