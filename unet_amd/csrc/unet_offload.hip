@@ -332,20 +332,25 @@ int unet_verify_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_
     HIP_TRY(hipSetDevice(ctx->device));
     Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
     const IfaceDev ifc = to_dev(iface);
-    constexpr int kVerifyTile = 16;
-    const int tile_env = getenv("UNET_VERIFY_TILE") ? atoi(getenv("UNET_VERIFY_TILE")) : kVerifyTile;
+    // Records per wave: long records want short tiles (fine-grained tail of the launch), short records
+    // want many lanes busy in the lane-parallel phase.
+    const u64 mean_len = arena_bytes / n;
+    int tile = mean_len >= 1024 ? 16 : (mean_len >= 256 ? 32 : 64);
+    if (const char* e = getenv("UNET_VERIFY_TILE")) tile = atoi(e);
     hipStream_t s = pick(ctx, stream);
+#define UNET_LAUNCH_VERIFY(M, T) \
+    hipLaunchKernelGGL((k_verify<M, T>), dim3(tiles_grid(n, T)), dim3(kBlock), 0, s, b, ifc, (u32*)d_out)
     if (iface->mode == UNET_MODE_L2) {
-        hipLaunchKernelGGL((k_verify<MODE_L2, kVerifyTile>), dim3(tiles_grid(n, kVerifyTile)), dim3(kBlock), 0, s, b, ifc, (u32*)d_out);
-    } else if (tile_env == 64) {
-        hipLaunchKernelGGL((k_verify<MODE_L3, 64>), dim3(tiles_grid(n, 64)), dim3(kBlock), 0, s, b, ifc, (u32*)d_out);
-    } else if (tile_env == 32) {
-        hipLaunchKernelGGL((k_verify<MODE_L3, 32>), dim3(tiles_grid(n, 32)), dim3(kBlock), 0, s, b, ifc, (u32*)d_out);
-    } else if (tile_env == 8) {
-        hipLaunchKernelGGL((k_verify<MODE_L3, 8>), dim3(tiles_grid(n, 8)), dim3(kBlock), 0, s, b, ifc, (u32*)d_out);
+        if (tile <= 16) UNET_LAUNCH_VERIFY(MODE_L2, 16);
+        else if (tile <= 32) UNET_LAUNCH_VERIFY(MODE_L2, 32);
+        else UNET_LAUNCH_VERIFY(MODE_L2, 64);
     } else {
-        hipLaunchKernelGGL((k_verify<MODE_L3, kVerifyTile>), dim3(tiles_grid(n, kVerifyTile)), dim3(kBlock), 0, s, b, ifc, (u32*)d_out);
+        if (tile <= 8) UNET_LAUNCH_VERIFY(MODE_L3, 8);
+        else if (tile <= 16) UNET_LAUNCH_VERIFY(MODE_L3, 16);
+        else if (tile <= 32) UNET_LAUNCH_VERIFY(MODE_L3, 32);
+        else UNET_LAUNCH_VERIFY(MODE_L3, 64);
     }
+#undef UNET_LAUNCH_VERIFY
     HIP_TRY(hipGetLastError());
     return UNET_OK;
 }
