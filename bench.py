@@ -173,6 +173,15 @@ def main():
 
     if rank == 0:
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC passes of this same command (tools/pmc_traffic.py), if the
+        # committed measurement matches this workload and batch size
+        traffic = None
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(args.workload)
+            if rec and rec["frames"] == n:
+                traffic = rec["traffic_bytes"]
+        except (OSError, ValueError, KeyError):
+            pass
         line = {
             "metric": "Gpkt/s and achieved HBM GB/s, batched IPv4+TCP/UDP checksum+parse, 1500B",
             "value": n * world * args.steps / wall / 1e9,
@@ -193,7 +202,7 @@ def main():
                        "sharding": "disjoint index ranges per rank, no data-path collective; counters all-reduced (RCCL) after the timed region",
                        "inputs": "generated in HBM by unet_synth_dev before the timed region"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": kernel,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": kernel,
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "stream_read_GBps": stream_gbps, "frac_of_stream_read": achieved / stream_gbps},
             "hbm_GBps_all_gpus": alg_bytes * world * args.steps / wall / 1e9,
