@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 import unet_amd
-from unet_amd import Verdict
+from unet_amd import Verdict, shard
 
 SEED = 0x756E6574
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--ext-tcp", type=int, default=None, help="TCP extension on/off (default: on for imix only)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--frames", type=int, default=0, help="override frames per GPU")
+    ap.add_argument("--rotate", type=int, default=0, help="number of distinct batches cycled through (default: 6 for hdr20, else 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -95,26 +96,43 @@ def main():
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     assert stream, "need a non-null stream handle (NULL selects the library's private stream)"
-    first_idx = rank * n
+    first_idx, n = shard.rank_index_range(rank, world, n)
 
-    # ---- build the batch in HBM
-    off16, lens, nbytes = unet_amd.synth_layout(kind, SEED, first_idx, n)
-    d_arena = torch.empty(nbytes + 16, dtype=torch.uint8, device="cuda")
-    d_out = torch.zeros(n, dtype=torch.int32, device="cuda")
-    if kind == unet_amd.SYNTH_IPV4_HDR20:
-        d_off = d_len = None
-        ctx.synth_dev(kind, SEED, first_idx, n, ifc, None, None, d_arena.data_ptr(), nbytes, stream)
-        alg_bytes = n * 24  # 20 read + 4 written per header
-        step = lambda: ctx.ipv4_validate_dev(d_arena.data_ptr(), n, ifc, d_out.data_ptr(), stream)
-        kernel = "k_ipv4_validate"
-    else:
-        d_off = torch.from_numpy(off16).cuda()
-        d_len = torch.from_numpy(lens).cuda()
-        ctx.synth_dev(kind, SEED, first_idx, n, ifc, d_off.data_ptr(), d_len.data_ptr(), d_arena.data_ptr(), nbytes, stream)
-        alg_bytes = int(lens.astype(np.int64).sum()) + 8 * n  # record bytes + 4 (length) + 4 (result)
-        off_ptr = None if stride16 else d_off.data_ptr()
-        step = lambda: ctx.verify_dev(d_arena.data_ptr(), nbytes, off_ptr, stride16, d_len.data_ptr(), n, ifc, d_out.data_ptr(), stream)
-        kernel = "k_verify<MODE_L3>"
+    # ---- build the batch(es) in HBM.  A workload whose arena is not far larger than the 256 MiB Infinity
+    # Cache is rotated over several distinct batches (consecutive index ranges of the same trace) so that
+    # no launch finds its input in cache.
+    rotate = args.rotate if args.rotate else (6 if kind == unet_amd.SYNTH_IPV4_HDR20 else 1)
+    steps_fns, keep = [], []
+    for r in range(rotate):
+        f_idx = first_idx + r * world * n
+        off16, lens, nbytes = unet_amd.synth_layout(kind, SEED, f_idx, n)
+        d_arena = torch.empty(nbytes + 16, dtype=torch.uint8, device="cuda")
+        d_out = torch.zeros(n, dtype=torch.int32, device="cuda")
+        if kind == unet_amd.SYNTH_IPV4_HDR20:
+            ctx.synth_dev(kind, SEED, f_idx, n, ifc, None, None, d_arena.data_ptr(), nbytes, stream)
+            alg_bytes = n * 24  # 20 read + 4 written per header
+            fn = (lambda a=d_arena, o=d_out: ctx.ipv4_validate_dev(a.data_ptr(), n, ifc, o.data_ptr(), stream))
+            kernel = "k_ipv4_validate"
+        else:
+            d_off = torch.from_numpy(off16).cuda()
+            d_len = torch.from_numpy(lens).cuda()
+            ctx.synth_dev(kind, SEED, f_idx, n, ifc, d_off.data_ptr(), d_len.data_ptr(), d_arena.data_ptr(), nbytes, stream)
+            alg_bytes = int(lens.astype(np.int64).sum()) + 8 * n  # record bytes + 4 (length) + 4 (result)
+            off_ptr = None if stride16 else d_off.data_ptr()
+            fn = (lambda a=d_arena, o=d_out, l=d_len, op=off_ptr, nb=nbytes:
+                  ctx.verify_dev(a.data_ptr(), nb, op, stride16, l.data_ptr(), n, ifc, o.data_ptr(), stream))
+            kernel = "k_verify<MODE_L3>"
+            keep.append((d_off, d_len))
+        steps_fns.append(fn)
+        keep.append((d_arena, d_out))
+        if r == 0:
+            d_arena0, d_out0, nbytes0, alg_bytes0 = d_arena, d_out, nbytes, alg_bytes
+    d_arena, d_out, nbytes, alg_bytes = d_arena0, d_out0, nbytes0, alg_bytes0
+    counter = [0]
+
+    def step():
+        steps_fns[counter[0] % rotate]()
+        counter[0] += 1
     torch.cuda.synchronize()
 
     # ---- timed region
@@ -136,19 +154,14 @@ def main():
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
-    if dist:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    wall = shard.max_over_ranks(wall, "cuda", dist)
 
     # ---- epilogue: per-verdict counters, summed across GPUs (the only cross-GPU traffic)
     d_cnt = torch.zeros(32, dtype=torch.int64, device="cuda")
     ctx.count_verdicts_dev(d_out.data_ptr(), n, d_cnt.data_ptr(), stream)
     torch.cuda.synchronize()
     local_cnt = d_cnt.cpu().numpy().copy()
-    if dist:
-        dist.all_reduce(d_cnt, op=dist.ReduceOp.SUM)
-    cnt = d_cnt.cpu().numpy()
+    cnt = shard.allreduce_counts(d_cnt, dist).cpu().numpy()
     parity = None
     if args.workload == "udp1500":
         # per-index fault rules of the trace: idx % 256 == 33 -> length mismatch; idx % 64 == 7 or
@@ -198,7 +211,7 @@ def main():
             "config": {"workload": {"udp1500": "4,194,304 x 1500-byte IPv4/UDP packets per GPU (BASELINE configs[2])",
                                     "imix": "8,388,608 mixed 64-9000-byte TCP/UDP/ICMP packets per GPU (BASELINE configs[3])",
                                     "hdr20": "16,777,216 bare 20-byte IPv4 headers per GPU (BASELINE configs[1])"}[args.workload],
-                       "frames_per_gpu": n, "arena_bytes_per_gpu": nbytes, "ext_tcp": ext_tcp,
+                       "frames_per_gpu": n, "arena_bytes_per_gpu": nbytes, "ext_tcp": ext_tcp, "batches_rotated": rotate,
                        "sharding": "disjoint index ranges per rank, no data-path collective; counters all-reduced (RCCL) after the timed region",
                        "inputs": "generated in HBM by unet_synth_dev before the timed region"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -333,35 +333,36 @@ __global__ __launch_bounds__(kBlock, 6) void k_verify(Batch b, IfaceDev ifc, u32
 }
 
 // ------------------------------------ a2-a4: Ipv4Header::try_from + validate, bare headers
-// 20-byte records back to back.  A block stages kHdrPerBlock headers (a multiple of 16 bytes)
-// through LDS with 16-byte coalesced loads; each thread then reads its headers as 5 dwords at a
-// 5-dword stride (odd stride: conflict-free on the 32-bank ds_read_b32 path).
-constexpr u32 kHdrPerThread = 4;
-constexpr u32 kHdrPerBlock = kBlock * kHdrPerThread;       // 1024 headers = 20480 bytes
-constexpr u32 kHdrChunksPerBlock = kHdrPerBlock * 20 / 16;  // 1280 chunks of 16 bytes
+// 20-byte records back to back.  Four headers are 80 bytes = five aligned 16-byte chunks, so a lane
+// owns G groups of four headers: 5*G dwordx4 loads, all issued before the first use (the wave's
+// instructions together cover one contiguous span, and with the default cache policy every line is
+// fetched from HBM once and then hit in L1 by the neighbouring lanes' chunks -- non-temporal loads
+// lose that reuse and run at 0.6x), twenty dwords per group in registers at compile-time offsets
+// 0/5/10/15, one dwordx4 store of four results per group.  No LDS, no barrier.
+constexpr u32 kHdrPerGroup = 4;
 
 __global__ __launch_bounds__(kBlock) void k_ipv4_validate(const uint8_t* __restrict__ hdrs, u32 n, u32 ext_tcp,
                                                           u32* __restrict__ out) {
-    __shared__ u32x4 stage[kHdrChunksPerBlock];
-    const u32 h0 = blockIdx.x * kHdrPerBlock;
-    const u64 total_chunks = ((u64)n * 20u + 15u) >> 4;  // host guarantees the buffer is padded to 16 bytes
-    const u64 c0 = (u64)blockIdx.x * kHdrChunksPerBlock;
-    const u32x4* src = reinterpret_cast<const u32x4*>(hdrs);
+    const u32 ngroups = (n + kHdrPerGroup - 1) / kHdrPerGroup;
+    for (u32 g = blockIdx.x * kBlock + threadIdx.x; g < ngroups; g += gridDim.x * kBlock) {
+        const u32 h0 = g * kHdrPerGroup;
+        if (h0 + kHdrPerGroup <= n) {
+            const u32x4* src = reinterpret_cast<const u32x4*>(hdrs) + (u64)g * 5u;
+            u32x4 d[5];
 #pragma unroll
-    for (u32 q = 0; q < kHdrChunksPerBlock / kBlock; ++q) {
-        const u32 c = q * kBlock + threadIdx.x;
-        u32x4 v = {0, 0, 0, 0};
-        if (c0 + c < total_chunks) v = src[c0 + c];
-        stage[c] = v;
-    }
-    __syncthreads();
-    const u32* w = reinterpret_cast<const u32*>(stage);
-#pragma unroll
-    for (u32 q = 0; q < kHdrPerThread; ++q) {
-        const u32 h = q * kBlock + threadIdx.x;
-        if (h0 + h < n) {
-            const u32* r = w + h * 5u;
-            out[h0 + h] = ipv4_header_verdict(r[0], r[1], r[2], r[3], r[4], ext_tcp);
+            for (int k = 0; k < 5; ++k) d[k] = src[k];
+            const u32 w[20] = {d[0].x, d[0].y, d[0].z, d[0].w, d[1].x, d[1].y, d[1].z, d[1].w, d[2].x, d[2].y,
+                               d[2].z, d[2].w, d[3].x, d[3].y, d[3].z, d[3].w, d[4].x, d[4].y, d[4].z, d[4].w};
+            u32x4 r;
+            r.x = ipv4_header_verdict(w[0], w[1], w[2], w[3], w[4], ext_tcp);
+            r.y = ipv4_header_verdict(w[5], w[6], w[7], w[8], w[9], ext_tcp);
+            r.z = ipv4_header_verdict(w[10], w[11], w[12], w[13], w[14], ext_tcp);
+            r.w = ipv4_header_verdict(w[15], w[16], w[17], w[18], w[19], ext_tcp);
+            __builtin_nontemporal_store(r, reinterpret_cast<u32x4*>(out + h0));
+        } else {
+            // last 1..3 headers of the batch: dword loads, nothing beyond byte 20*n is touched
+            const u32* w = reinterpret_cast<const u32*>(hdrs) + (u64)h0 * 5u;
+            for (u32 h = h0; h < n; ++h, w += 5) out[h] = ipv4_header_verdict(w[0], w[1], w[2], w[3], w[4], ext_tcp);
         }
     }
 }

@@ -296,9 +296,13 @@ int unet_ipv4_validate_dev(unet_ctx* ctx, void* stream, const uint8_t* d_hdrs, u
     if (!d_hdrs || !iface || !d_out) return fail(UNET_E_INVAL, "null argument");
     if (((uintptr_t)d_hdrs & 15u) != 0) return fail(UNET_E_INVAL, "header buffer must be 16-byte aligned");
     HIP_TRY(hipSetDevice(ctx->device));
-    const u32 grid = (n + kHdrPerBlock - 1) / kHdrPerBlock;
+    if (((uintptr_t)d_out & 15u) != 0) return fail(UNET_E_INVAL, "result buffer must be 16-byte aligned");
+    const u32 per_block = kBlock * kHdrPerGroup;
+    u32 grid = (n + per_block - 1) / per_block;
+    const u32 cap = getenv("UNET_HDR_GRID") ? (u32)atoi(getenv("UNET_HDR_GRID")) : 0xffffffffu;
+    if (grid > cap) grid = cap;
     hipLaunchKernelGGL(k_ipv4_validate, dim3(grid), dim3(kBlock), 0, pick(ctx, stream), d_hdrs, n,
-                       (u32)(iface->ext_tcp ? 1 : 0), (u32*)d_out);
+                       iface->ext_tcp ? 1u : 0u, (u32*)d_out);
     HIP_TRY(hipGetLastError());
     return UNET_OK;
 }
