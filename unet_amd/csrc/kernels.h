@@ -1,6 +1,6 @@
-// gfx950 kernels of the offload.  All of them are HBM-bound byte/integer work: 16-byte
-// coalesced loads, one v_sad_u16 per dword, DPP wave reductions, no LDS except where a
-// record is not a multiple of 16 bytes (the bare 20-byte header kernel).
+// gfx950 kernels of the offload.  All of them are HBM-bound byte/integer work: 16-byte coalesced
+// loads, one v_sad_u16 per dword, DPP wave reductions; LDS only parks the few header bytes that the
+// per-record decision logic reads back lane-parallel.
 #pragma once
 #include "csum_core.h"
 #include "parse.h"
@@ -8,7 +8,6 @@
 
 namespace unetdev {
 
-constexpr u32 kTile = 64;        // records per wave: lane j keeps record j's metadata and result
 constexpr u32 kBlock = 256;      // 4 waves
 constexpr u32 kMaxLen = 65535;   // IPv4 maximum (src/protocols/ipv4.rs:18), loopback MTU (src/devices/loopback.rs:16)
 
@@ -22,75 +21,39 @@ struct Batch {
     u32 n;
 };
 
-// Header dwords of the record a wave is working on, held in row 0 (chunk `lane` of the record).
-struct WaveFetch {
-    u32x4 r;
-    __device__ __forceinline__ u32 operator()(u32 k) const {
-        const u32 l = k >> 2, s = k & 3u;
-        const u32 x = rdlane(r.x, l), y = rdlane(r.y, l), z = rdlane(r.z, l), w = rdlane(r.w, l);
-        return s == 0u ? x : (s == 1u ? y : (s == 2u ? z : w));
-    }
-};
-
-// Per-lane tail masking of the last 16-byte chunk of a record (bytes at and beyond `flen` are
-// pad and must not be summed).  m[] are wave-uniform.
-struct TailMask {
-    u32 last;  // index of the last chunk
-    u32 m0, m1, m2, m3;
-    __device__ __forceinline__ TailMask(u32 flen, u32 nch) {
-        last = nch - 1u;
-        const int tb = (int)(flen - last * 16u);  // 1..16 valid bytes in the last chunk
-        m0 = keep_bytes(tb);
-        m1 = keep_bytes(tb - 4);
-        m2 = keep_bytes(tb - 8);
-        m3 = keep_bytes(tb - 12);
-    }
-    __device__ __forceinline__ u32x4 apply(u32x4 v, u32 chunk) const {
-        if (chunk == last) {
-            v.x &= m0;
-            v.y &= m1;
-            v.z &= m2;
-            v.w &= m3;
-        }
-        return v;
-    }
-};
-
 // Record bytes are read exactly once and never reused: non-temporal 16-byte loads keep them from
 // displacing anything in L2 / Infinity Cache (measured on MI355X: 7.0 TB/s streaming read with
 // them against 6.2 TB/s with default-policy loads).
 __device__ __forceinline__ u32x4 ld_stream(const u32x4* p) { return __builtin_nontemporal_load(p); }
 
-// `p` points at the record, `nch` = ceil(flen / 16).
-// Rows from chunk `from` on, four 1 KiB loads in flight per iteration; per-lane partial sums.
-__device__ __forceinline__ u32 rows_sum(const u32x4* __restrict__ p, u32 nch, u32 from, const TailMask& tm, u32 lane, u32 acc) {
-    for (u32 c0 = from; c0 < nch; c0 += 4u * kWave) {
-        const u32 i0 = c0 + lane, i1 = i0 + kWave, i2 = i1 + kWave, i3 = i2 + kWave;
-        u32x4 a = {0, 0, 0, 0}, b = a, c = a, d = a;
-        if (i0 < nch) a = ld_stream(p + i0);
-        if (i1 < nch) b = ld_stream(p + i1);
-        if (i2 < nch) c = ld_stream(p + i2);
-        if (i3 < nch) d = ld_stream(p + i3);
-        acc = sum_chunk(tm.apply(a, i0), acc);
-        acc = sum_chunk(tm.apply(b, i1), acc);
-        acc = sum_chunk(tm.apply(c, i2), acc);
-        acc = sum_chunk(tm.apply(d, i3), acc);
-    }
-    return acc;
-}
+// ------------------------------------------------------------------------------------------------
+// Tile machinery shared by k_verify, k_csum and k_generate.
+//
+// One wave owns TILE consecutive records; lane j keeps record j's length, slot and, at the end, its
+// exact byte-swapped-word sum over [0, len).  Work split inside the wave:
+//   * streaming, wave-cooperative, one record at a time (records longer than kSmallChunks chunks):
+//     all 64 lanes load the record in 16-byte chunks, sum the FULL chunks, and a DPP reduction leaves
+//     the sum in lane j.  Nothing here depends on the record's contents.  The first six chunks (every
+//     header byte any check can look at) and the partial last chunk are parked in LDS.
+//   * lane-parallel: records of at most kSmallChunks chunks are loaded and summed by their own lane;
+//     afterwards every lane adds the byte-masked tail chunk of its streamed record.
+// Callers then run their O(1)-per-record logic lane-parallel on headers read back from LDS, i.e. once
+// per tile on the vector unit instead of once per record on the (per-CU, shared) scalar unit.
+constexpr u32 kSmallChunks = 8;   // records <= 128 bytes are handled by a single lane
+constexpr u32 kHdrChunks = 6;     // 96 bytes: 14 (Ethernet) + 60 (max IPv4 header) + 16 (deepest L4 field) = 90
+constexpr u32 kLdsChunksPerRec = kHdrChunks + 1;  // + the record's partial last chunk
 
-__device__ __forceinline__ u32 record_sum(const u32x4* __restrict__ p, u32 flen, u32 nch, u32x4 row0, u32 lane) {
-    const TailMask tm(flen, nch);
-    const u32 acc = sum_chunk(tm.apply(row0, lane), 0u);
-    return wave_sum(rows_sum(p, nch, kWave, tm, lane, acc));
-}
+// Header dwords of a lane's own record, parked in LDS.
+struct LdsFetch {
+    const u32* w;
+    __device__ __forceinline__ u32 operator()(u32 k) const { return w[k]; }
+};
 
-// Tile bookkeeping shared by the wave-per-record kernels.
 struct Tile {
     u32 first, cnt, lane;
     u32 my_len, my_slot;
     bool my_ok;
-    template <int TILE = (int)kTile>
+    template <int TILE>
     __device__ __forceinline__ bool init(const Batch& b) {
         lane = threadIdx.x & 63u;
         const u32 wave = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
@@ -110,56 +73,6 @@ struct Tile {
         }
         return true;
     }
-};
-
-// ---------------------------------------------------------------- a1: calculate_checksum
-// out[i] = calculate_checksum(record i, seeds[i])  (src/utils.rs:1-17)
-__global__ __launch_bounds__(kBlock) void k_csum(Batch b, const uint16_t* __restrict__ seeds,
-                                                 uint16_t* __restrict__ out) {
-    Tile t;
-    if (!t.init(b)) return;
-    u32 my_seed = 0;
-    if (seeds && t.lane < t.cnt) my_seed = seeds[t.first + t.lane];
-    const u64 okmask = __ballot(t.my_ok);
-    u32 my_res = 0;
-    for (u32 j = 0; j < t.cnt; ++j) {
-        const u32 flen = rdlane(t.my_len, j);
-        const u32 slot = rdlane(t.my_slot, j);
-        const u32 seed = rdlane(my_seed, j);
-        if (!((okmask >> j) & 1ull)) continue;
-        u32 total = 0;
-        if (flen != 0u) {
-            const u32x4* p = reinterpret_cast<const u32x4*>(b.arena + (u64)slot * 16u);
-            const u32 nch = (flen + 15u) >> 4;
-            u32x4 r0 = {0, 0, 0, 0};
-            if (t.lane < nch) r0 = ld_stream(p + t.lane);
-            total = record_sum(p, flen, nch, r0, t.lane);
-        }
-        const u32 res = finish(total + bswap16(seed));
-        if (t.lane == j) my_res = res;
-    }
-    if (t.lane < t.cnt) out[t.first + t.lane] = (uint16_t)my_res;
-}
-
-// ------------------------------------------- a2-a6, a8, a11: receive-path verdicts
-//
-// Work split inside one wave (TILE consecutive records, lane j owns record j's metadata and result):
-//   * streaming, wave-cooperative, one record at a time (records longer than kSmallChunks chunks):
-//     all 64 lanes load the record in 16-byte chunks, sum the FULL chunks, and a DPP reduction leaves
-//     the exact sum in lane j.  Nothing here depends on the record's contents.  The first six chunks
-//     (every header byte any check can look at) and the partial last chunk are parked in LDS.
-//   * lane-parallel: records of at most kSmallChunks chunks are loaded and summed by their own lane;
-//     then every lane parses ITS record's headers out of LDS, adds the masked tail chunk, and turns
-//     sum + headers into the verdict.  The whole O(1)-per-record decision logic therefore runs once
-//     per tile on the vector unit instead of once per record on the (per-CU, shared) scalar unit.
-constexpr u32 kSmallChunks = 8;   // records <= 128 bytes are handled by a single lane
-constexpr u32 kHdrChunks = 6;     // 96 bytes: 14 (Ethernet) + 60 (max IPv4 header) + 16 (deepest L4 field) = 90
-constexpr u32 kLdsChunksPerRec = kHdrChunks + 1;  // + the record's partial last chunk
-
-// Header dwords of a lane's own record, parked in LDS.
-struct LdsFetch {
-    const u32* w;
-    __device__ __forceinline__ u32 operator()(u32 k) const { return w[k]; }
 };
 
 // Rows 0 and 1 (the first 2 KiB) of one record, as loaded by a whole wave.
@@ -198,11 +111,12 @@ __device__ __forceinline__ u32x4 zero_unless(u32x4 v, bool keep) {
 }
 
 // Sum of the full chunks of one streamed record (wave-uniform result); parks header and tail chunk.
+template <bool PARK_HDR>
 __device__ __forceinline__ u32 stream_one(const Rows2& cur, u32 lane, u32x4* __restrict__ park) {
-    const u32 nfull = cur.flen >> 4;         // chunks that are summed whole
+    const u32 nfull = cur.flen >> 4;              // chunks that are summed whole
     const bool partial = (cur.flen & 15u) != 0u;  // chunk `nfull` exists and is cut short
     u32x4* mine = park + cur.j * kLdsChunksPerRec;
-    if (lane < kHdrChunks) mine[lane] = cur.r0;
+    if (PARK_HDR && lane < kHdrChunks) mine[lane] = cur.r0;
     const u32 i0 = lane, i1 = lane + kWave;
     if (partial && nfull < kWave) {
         if (i0 == nfull) mine[kHdrChunks] = cur.r0;
@@ -214,19 +128,16 @@ __device__ __forceinline__ u32 stream_one(const Rows2& cur, u32 lane, u32x4* __r
     if (nfull < 2u * kWave) c = zero_unless(c, i1 < nfull);
     u32 acc = sum_chunk(a, 0u);
     acc = sum_chunk(c, acc);
-    for (u32 c0 = 2u * kWave; c0 < cur.nch; c0 += 4u * kWave) {
+    // beyond 2 KiB: four 1 KiB loads in flight per step, full chunks only (the cut chunk of such a
+    // record is fetched by its own lane afterwards)
+#pragma nounroll
+    for (u32 c0 = 2u * kWave; c0 < nfull; c0 += 4u * kWave) {
         const u32 k0 = c0 + lane, k1 = k0 + kWave, k2 = k1 + kWave, k3 = k2 + kWave;
         u32x4 v0 = {0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
-        if (k0 < cur.nch) v0 = ld_stream(cur.p + k0);
-        if (k1 < cur.nch) v1 = ld_stream(cur.p + k1);
-        if (k2 < cur.nch) v2 = ld_stream(cur.p + k2);
-        if (k3 < cur.nch) v3 = ld_stream(cur.p + k3);
-        if (partial && nfull >= c0 && nfull < c0 + 4u * kWave) {  // the cut chunk is in this group
-            if (k0 == nfull) { mine[kHdrChunks] = v0; v0 = u32x4{0, 0, 0, 0}; }
-            if (k1 == nfull) { mine[kHdrChunks] = v1; v1 = u32x4{0, 0, 0, 0}; }
-            if (k2 == nfull) { mine[kHdrChunks] = v2; v2 = u32x4{0, 0, 0, 0}; }
-            if (k3 == nfull) { mine[kHdrChunks] = v3; v3 = u32x4{0, 0, 0, 0}; }
-        }
+        if (k0 < nfull) v0 = ld_stream(cur.p + k0);
+        if (k1 < nfull) v1 = ld_stream(cur.p + k1);
+        if (k2 < nfull) v2 = ld_stream(cur.p + k2);
+        if (k3 < nfull) v3 = ld_stream(cur.p + k3);
         acc = sum_chunk(v0, acc);
         acc = sum_chunk(v1, acc);
         acc = sum_chunk(v2, acc);
@@ -254,16 +165,14 @@ struct LaneTail {
     }
 };
 
-template <int MODE, int TILE>
-__global__ __launch_bounds__(kBlock, 6) void k_verify(Batch b, IfaceDev ifc, u32* __restrict__ out) {
-    static_assert(TILE >= 1 && TILE <= 64, "one lane per record of the tile");
-    __shared__ u32x4 lds[(kBlock / kWave) * TILE * kLdsChunksPerRec];
-    Tile t;
-    if (!t.init<TILE>(b)) return;
-    u32x4* park = lds + (threadIdx.x >> 6) * (TILE * kLdsChunksPerRec);
+// Exact sum of the lane's own record (0 for lanes without a valid record).  On return the wave's LDS
+// area `park` holds, for record j, chunks 0..5 at park[j*7 .. j*7+5] (if PARK_HDR) -- visible to every
+// lane of the wave.
+template <int TILE, bool PARK_HDR>
+__device__ __forceinline__ u32 tile_sums(const Batch& b, const Tile& t, u32x4* __restrict__ park) {
     u32x4* mine = park + t.lane * kLdsChunksPerRec;  // only meaningful for lane < TILE
     const u32 my_nch = t.my_ok ? (t.my_len + 15u) >> 4 : 0u;
-    const bool my_small = t.my_ok && my_nch <= kSmallChunks;
+    const bool my_small = t.my_ok && my_nch >= 1u && my_nch <= kSmallChunks;
     const bool my_big = t.my_ok && my_nch > kSmallChunks;
     const LaneTail tail(t.my_len);
     const bool my_partial = (t.my_len & 15u) != 0u;
@@ -279,55 +188,112 @@ __global__ __launch_bounds__(kBlock, 6) void k_verify(Batch b, IfaceDev ifc, u32
         A = issue_rows(b, t.my_len, t.my_slot, t.lane, jA, true);
     }
 
-    // ---- lane-parallel records: each lane pulls its own <= 8 chunks
+    // ---- the cut last chunk of a record longer than 2 KiB is not held in rows 0/1: its own lane
+    // fetches it now, long before it is needed
+    const bool my_far = my_big && my_partial && (t.my_len >> 4) >= 2u * kWave;
+    u32x4 far_cut = {0, 0, 0, 0};
+    if (my_far) far_cut = ld_stream(reinterpret_cast<const u32x4*>(b.arena + (u64)t.my_slot * 16u) + (t.my_len >> 4));
+
+    // ---- lane-parallel records: each lane pulls its own 1..8 chunks.  Straight-line code per group
+    // of four: unconditional loads (indices past the end re-read the last chunk and are zeroed by
+    // selects), so all of them are in flight together and no wide value is merged across branches.
     if (my_small) {
         const u32x4* p = reinterpret_cast<const u32x4*>(b.arena + (u64)t.my_slot * 16u);
-        u32x4 c[kSmallChunks];
-#pragma unroll
-        for (u32 i = 0; i < kSmallChunks; ++i) {
-            c[i] = u32x4{0, 0, 0, 0};
-            if (i < my_nch) c[i] = ld_stream(p + i);
+        const u32 last = my_nch - 1u;
+        const u32 k0 = my_partial ? tail.m0 : 0xffffffffu, k1 = my_partial ? tail.m1 : 0xffffffffu;
+        const u32 k2 = my_partial ? tail.m2 : 0xffffffffu, k3 = my_partial ? tail.m3 : 0xffffffffu;
+        u32 acc = 0;
+#define UNET_SMALL_LOAD(i) const u32x4 s##i = ld_stream(p + min((u32)(i), last))
+#define UNET_SMALL_USE(i)                                                           \
+        {                                                                           \
+            if (PARK_HDR && (i) < kHdrChunks) mine[i] = s##i;                       \
+            const bool in = (u32)(i) <= last, cut = (u32)(i) == last;               \
+            u32x4 v = zero_unless(s##i, in);                                        \
+            v.x &= cut ? k0 : 0xffffffffu;                                          \
+            v.y &= cut ? k1 : 0xffffffffu;                                          \
+            v.z &= cut ? k2 : 0xffffffffu;                                          \
+            v.w &= cut ? k3 : 0xffffffffu;                                          \
+            acc = sum_chunk(v, acc);                                                \
         }
-        const u32 last = my_nch - 1u;  // my_nch == 0 never matches below
-#pragma unroll
-        for (u32 i = 0; i < kSmallChunks; ++i) {
-            if (i < kHdrChunks) mine[i] = c[i];
-            u32x4 v = c[i];
-            if (my_partial && i == last) v = tail.apply(v);
-            my_total = sum_chunk(v, my_total);
+        UNET_SMALL_LOAD(0); UNET_SMALL_LOAD(1); UNET_SMALL_LOAD(2); UNET_SMALL_LOAD(3);
+        if (last >= 4u) {  // 65..128 bytes
+            UNET_SMALL_LOAD(4); UNET_SMALL_LOAD(5); UNET_SMALL_LOAD(6); UNET_SMALL_LOAD(7);
+            UNET_SMALL_USE(4) UNET_SMALL_USE(5) UNET_SMALL_USE(6) UNET_SMALL_USE(7)
         }
+        UNET_SMALL_USE(0) UNET_SMALL_USE(1) UNET_SMALL_USE(2) UNET_SMALL_USE(3)
+#undef UNET_SMALL_LOAD
+#undef UNET_SMALL_USE
+        my_total = acc;
     }
 
-    // ---- stream the long records, two register buffers used alternately
+    // ---- stream the long records, two register buffers used alternately (no register copies, so
+    // nothing forces an early wait)
     if (A.live) {
+#pragma nounroll
         while (true) {
             const bool hasB = todo != 0ull;
             const u32 jB = hasB ? (u32)__builtin_ctzll(todo) : A.j;
             todo &= todo - 1ull;
             B = issue_rows(b, t.my_len, t.my_slot, t.lane, jB, hasB);
-            const u32 sA = stream_one(A, t.lane, park);
+            const u32 sA = stream_one<PARK_HDR>(A, t.lane, park);
             if (t.lane == A.j) my_total = sA;
             if (!hasB) break;
             const bool hasA = todo != 0ull;
             const u32 jA = hasA ? (u32)__builtin_ctzll(todo) : B.j;
             todo &= todo - 1ull;
             A = issue_rows(b, t.my_len, t.my_slot, t.lane, jA, hasA);
-            const u32 sB = stream_one(B, t.lane, park);
+            const u32 sB = stream_one<PARK_HDR>(B, t.lane, park);
             if (t.lane == B.j) my_total = sB;
             if (!hasA) break;
         }
     }
 
-    // ---- every lane finishes its own record: headers and tail chunk come back out of LDS
+    // ---- LDS written by other lanes of this wave is read back below and by the caller
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (my_big && my_partial) {
+        const u32 nfull = t.my_len >> 4;
+        // parked by the wave while it held rows 0/1, or fetched by this lane at the top
+        const u32x4 cut = nfull < 2u * kWave ? mine[kHdrChunks] : far_cut;
+        my_total = sum_chunk(tail.apply(cut), my_total);
+    }
+    return my_total;
+}
+
+#define UNET_TILE_LDS(TILE) __shared__ u32x4 lds[(kBlock / kWave) * (TILE) * kLdsChunksPerRec]; \
+    u32x4* park = lds + (threadIdx.x >> 6) * ((TILE) * kLdsChunksPerRec)
+
+// ---------------------------------------------------------------- a1: calculate_checksum
+// out[i] = calculate_checksum(record i, seeds[i])  (src/utils.rs:1-17)
+template <int TILE>
+__global__ __launch_bounds__(kBlock, TILE == 64 ? 5 : 6) void k_csum(Batch b, const uint16_t* __restrict__ seeds,
+                                                    uint16_t* __restrict__ out) {
+    static_assert(TILE >= 1 && TILE <= 64, "one lane per record of the tile");
+    UNET_TILE_LDS(TILE);
+    Tile t;
+    if (!t.init<TILE>(b)) return;
+    u32 my_seed = 0;
+    if (seeds && t.lane < t.cnt) my_seed = seeds[t.first + t.lane];
+    const u32 total = tile_sums<TILE, false>(b, t, park);
+    // the seed is an already-folded partial sum in the big-endian domain (src/utils.rs:2)
+    const u32 res = t.my_ok ? finish(total + bswap16(my_seed)) : 0u;
+    if (t.lane < t.cnt) out[t.first + t.lane] = (uint16_t)res;
+}
+
+// ------------------------------------------- a2-a6, a8, a11: receive-path verdicts
+template <int MODE, int TILE>
+__global__ __launch_bounds__(kBlock, TILE == 64 ? 5 : 6) void k_verify(Batch b, IfaceDev ifc, u32* __restrict__ out) {
+    static_assert(TILE >= 1 && TILE <= 64, "one lane per record of the tile");
+    UNET_TILE_LDS(TILE);
+    Tile t;
+    if (!t.init<TILE>(b)) return;
+    const u32 total = tile_sums<TILE, true>(b, t, park);
     u32 res = 0;  // V_NONE for records whose length/offset is out of range
     if (t.my_ok) {
-        if (my_big && my_partial) my_total = sum_chunk(tail.apply(mine[kHdrChunks]), my_total);
         LdsFetch f;
-        f.w = reinterpret_cast<const u32*>(mine);
+        f.w = reinterpret_cast<const u32*>(park + t.lane * kLdsChunksPerRec);
         const Parsed P = parse_record<MODE>(f, t.my_len, ifc);
-        res = P.kind == K_DONE ? P.res : finalize_record(P, my_total);
+        res = P.kind == K_DONE ? P.res : finalize_record(P, total);
     }
     if (t.lane < t.cnt) out[t.first + t.lane] = res;
 }
@@ -368,64 +334,50 @@ __global__ __launch_bounds__(kBlock) void k_ipv4_validate(const uint8_t* __restr
 }
 
 // ------------------------------- a7, a9, a10: transmit-side checksum fill, in place
-// status[i] = 0 when filled, else the reason the record was left alone.
-__global__ __launch_bounds__(kBlock) void k_generate(Batch b, uint8_t* __restrict__ arena_rw,
-                                                     uint8_t* __restrict__ status) {
+// status[i] = 0 when filled, else the reason the record was left alone.  The sums are taken over the
+// packet as it stands; the stale contents of the checksum fields are subtracted exactly.
+template <int TILE>
+__global__ __launch_bounds__(kBlock, TILE == 64 ? 5 : 6) void k_generate(Batch b, uint8_t* __restrict__ arena_rw,
+                                                        uint8_t* __restrict__ status) {
+    static_assert(TILE >= 1 && TILE <= 64, "one lane per record of the tile");
+    UNET_TILE_LDS(TILE);
     Tile t;
-    if (!t.init(b)) return;
-    const u64 okmask = __ballot(t.my_ok);
-    u32 my_st = V_NONE;
-    for (u32 j = 0; j < t.cnt; ++j) {
-        const u32 flen = rdlane(t.my_len, j);
-        const u32 slot = rdlane(t.my_slot, j);
-        if (!((okmask >> j) & 1ull)) { if (t.lane == j) my_st = V_DROP_L3_TRUNCATED; continue; }
-        const u32x4* p = reinterpret_cast<const u32x4*>(b.arena + (u64)slot * 16u);
-        uint8_t* rec = arena_rw + (u64)slot * 16u;
-        const u32 nch = (flen + 15u) >> 4;
-        WaveFetch f;
-        f.r = u32x4{0, 0, 0, 0};
-        if (t.lane < nch) f.r = p[t.lane];
-        u32 st = 0;
-        if (flen < 20u) {
-            st = V_DROP_L3_TRUNCATED;
-        } else {
-            const u32 w0 = f(0), w1 = f(1), w2 = f(2), w3 = f(3), w4 = f(4);
-            const u32 proto = (w2 >> 8) & 0xffu;
-            const u32 vhl = w0 & 0xffu;
-            const u32 seglen = flen - 20u;
-            if (!(proto == 1u || proto == 17u)) st = V_DROP_L3_PROTO;
-            else if ((vhl >> 4) != 4u) st = V_DROP_L3_VERSION;
-            else if ((vhl & 0xfu) < 5u) st = V_DROP_L3_IHL_SHORT;
-            else if ((vhl & 0xfu) > 5u) st = V_DROP_L3_IHL_LONG;
-            else if (seglen < 8u) st = proto == 17u ? V_DROP_UDP_SHORT : V_DROP_ICMP_TRUNCATED;
-            else {
-                const u32 total = record_sum(p, flen, nch, f.r, t.lane);
-                // IPv4 header field zeroed, then summed (src/protocols/ipv4.rs:374-389)
-                const u32 hdr = halves(w0) + halves(w1) + (w2 & 0xffffu) + halves(w3) + halves(w4);
-                const u32 ipck = finish(hdr);
-                const u32 prefix = hdr + (w2 >> 16);
-                u32 l4ck, l4off;
-                if (proto == 17u) {
-                    // s = ck(pseudo, 0); c = ck(hdr(cksum 0) || payload, !s)  (src/transport/udp.rs:200-203)
-                    const u32 u1 = f(6);
-                    const u32 pseudo = halves(w3) + halves(w4) + 0x1100u + bswap16(seglen);
-                    l4ck = finish(total - prefix - (u1 >> 16) + pseudo);
-                    l4off = 26u;
-                } else {
-                    // ck(hdr(cksum 0) || data, 0)  (src/transport/icmp.rs:81-85)
-                    const u32 m0 = f(5);
-                    l4ck = finish(total - prefix - (m0 >> 16));
-                    l4off = 22u;
-                }
-                if (t.lane == 0u) {
-                    *reinterpret_cast<uint16_t*>(rec + 10) = (uint16_t)bswap16(ipck);
-                    *reinterpret_cast<uint16_t*>(rec + l4off) = (uint16_t)bswap16(l4ck);
-                }
+    if (!t.init<TILE>(b)) return;
+    const u32 total = tile_sums<TILE, true>(b, t, park);
+    u32 st = V_DROP_L3_TRUNCATED;  // also reported for out-of-range lengths/offsets
+    if (t.my_ok && t.my_len >= 20u) {
+        const u32* w = reinterpret_cast<const u32*>(park + t.lane * kLdsChunksPerRec);
+        const u32 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+        const u32 proto = (w2 >> 8) & 0xffu;
+        const u32 vhl = w0 & 0xffu;
+        const u32 seglen = t.my_len - 20u;
+        if (!(proto == 1u || proto == 17u)) st = V_DROP_L3_PROTO;
+        else if ((vhl >> 4) != 4u) st = V_DROP_L3_VERSION;
+        else if ((vhl & 0xfu) < 5u) st = V_DROP_L3_IHL_SHORT;
+        else if ((vhl & 0xfu) > 5u) st = V_DROP_L3_IHL_LONG;
+        else if (seglen < 8u) st = proto == 17u ? V_DROP_UDP_SHORT : V_DROP_ICMP_TRUNCATED;
+        else {
+            st = 0;
+            uint8_t* rec = arena_rw + (u64)t.my_slot * 16u;
+            // IPv4 header field zeroed, then summed (src/protocols/ipv4.rs:374-389)
+            const u32 hdr = halves(w0) + halves(w1) + (w2 & 0xffffu) + halves(w3) + halves(w4);
+            const u32 prefix = hdr + (w2 >> 16);
+            u32 l4ck, l4off;
+            if (proto == 17u) {
+                // s = ck(pseudo, 0); c = ck(hdr(cksum 0) || payload, !s)  (src/transport/udp.rs:200-203)
+                const u32 pseudo = halves(w3) + halves(w4) + 0x1100u + bswap16(seglen);
+                l4ck = finish(total - prefix - (w[6] >> 16) + pseudo);
+                l4off = 26u;
+            } else {
+                // ck(hdr(cksum 0) || data, 0)  (src/transport/icmp.rs:81-85)
+                l4ck = finish(total - prefix - (w[5] >> 16));
+                l4off = 22u;
             }
+            *reinterpret_cast<uint16_t*>(rec + 10) = (uint16_t)bswap16(finish(hdr));
+            *reinterpret_cast<uint16_t*>(rec + l4off) = (uint16_t)bswap16(l4ck);
         }
-        if (t.lane == j) my_st = st;
     }
-    if (status && t.lane < t.cnt) status[t.first + t.lane] = (uint8_t)my_st;
+    if (status && t.lane < t.cnt) status[t.first + t.lane] = (uint8_t)st;
 }
 
 // ------------------------------------------------------------------ verdict histogram

@@ -122,9 +122,19 @@ int check_batch(unet_ctx* ctx, const void* arena, const void* off16, u32 stride1
 }
 // the kernels may touch the arena's first 16 bytes even when every record is empty
 inline bool arena_too_small(u64 arena_bytes) { return arena_bytes < 16; }
+// Records per wave: long records want short tiles (fine-grained tail of the launch), short records
+// want many lanes busy in the lane-parallel phase.
+inline int pick_tile(u64 arena_bytes, u32 n) {
+    if (const char* e = getenv("UNET_TILE")) {
+        const int t = atoi(e);
+        return t <= 16 ? 16 : (t <= 32 ? 32 : 64);
+    }
+    const u64 mean_len = arena_bytes / n;
+    return mean_len >= 1024 ? 16 : (mean_len >= 256 ? 32 : 64);
+}
 
 inline hipStream_t pick(unet_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->s_comp; }
-inline u32 tiles_grid(u32 n, u32 tile = kTile) {
+inline u32 tiles_grid(u32 n, u32 tile) {
     const u32 tiles = (n + tile - 1) / tile;
     return (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
 }
@@ -232,7 +242,12 @@ int unet_csum_batch_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uin
     if (!d_out) return fail(UNET_E_INVAL, "null output");
     HIP_TRY(hipSetDevice(ctx->device));
     Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
-    hipLaunchKernelGGL(k_csum, dim3(tiles_grid(n)), dim3(kBlock), 0, pick(ctx, stream), b, d_seeds, d_out);
+    if (arena_too_small(arena_bytes)) return fail(UNET_E_INVAL, "arena must hold at least 16 bytes");
+    switch (pick_tile(arena_bytes, n)) {
+        case 16: hipLaunchKernelGGL(k_csum<16>, dim3(tiles_grid(n, 16)), dim3(kBlock), 0, pick(ctx, stream), b, d_seeds, d_out); break;
+        case 32: hipLaunchKernelGGL(k_csum<32>, dim3(tiles_grid(n, 32)), dim3(kBlock), 0, pick(ctx, stream), b, d_seeds, d_out); break;
+        default: hipLaunchKernelGGL(k_csum<64>, dim3(tiles_grid(n, 64)), dim3(kBlock), 0, pick(ctx, stream), b, d_seeds, d_out); break;
+    }
     HIP_TRY(hipGetLastError());
     return UNET_OK;
 }
@@ -281,7 +296,7 @@ int unet_csum(unet_ctx* c, const uint8_t* data, size_t len, uint16_t seed, uint1
     HIP_TRY(hipMemcpyAsync(c->d_arena.p, pin, padded ? padded : 16, hipMemcpyHostToDevice, c->s_comp));
     HIP_TRY(hipMemcpyAsync(c->d_len.p, pin + padded, 8, hipMemcpyHostToDevice, c->s_comp));
     HIP_TRY(hipEventRecord(c->pinned_free[0], c->s_comp));
-    rc = unet_csum_batch_dev(c, nullptr, (const uint8_t*)c->d_arena.p, padded, nullptr, 1, (const u32*)c->d_len.p,
+    rc = unet_csum_batch_dev(c, nullptr, (const uint8_t*)c->d_arena.p, padded ? padded : 16, nullptr, 1, (const u32*)c->d_len.p,
                              (const uint16_t*)((const uint8_t*)c->d_len.p + 4), 1, (uint16_t*)c->d_out.p);
     if (rc) return rc;
     return d2h_sync(c, out, c->d_out.p, 2);
@@ -298,9 +313,7 @@ int unet_ipv4_validate_dev(unet_ctx* ctx, void* stream, const uint8_t* d_hdrs, u
     HIP_TRY(hipSetDevice(ctx->device));
     if (((uintptr_t)d_out & 15u) != 0) return fail(UNET_E_INVAL, "result buffer must be 16-byte aligned");
     const u32 per_block = kBlock * kHdrPerGroup;
-    u32 grid = (n + per_block - 1) / per_block;
-    const u32 cap = getenv("UNET_HDR_GRID") ? (u32)atoi(getenv("UNET_HDR_GRID")) : 0xffffffffu;
-    if (grid > cap) grid = cap;
+    const u32 grid = (n + per_block - 1) / per_block;
     hipLaunchKernelGGL(k_ipv4_validate, dim3(grid), dim3(kBlock), 0, pick(ctx, stream), d_hdrs, n,
                        iface->ext_tcp ? 1u : 0u, (u32*)d_out);
     HIP_TRY(hipGetLastError());
@@ -336,22 +349,17 @@ int unet_verify_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_
     HIP_TRY(hipSetDevice(ctx->device));
     Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
     const IfaceDev ifc = to_dev(iface);
-    // Records per wave: long records want short tiles (fine-grained tail of the launch), short records
-    // want many lanes busy in the lane-parallel phase.
-    const u64 mean_len = arena_bytes / n;
-    int tile = mean_len >= 1024 ? 16 : (mean_len >= 256 ? 32 : 64);
-    if (const char* e = getenv("UNET_VERIFY_TILE")) tile = atoi(e);
+    const int tile = pick_tile(arena_bytes, n);
     hipStream_t s = pick(ctx, stream);
 #define UNET_LAUNCH_VERIFY(M, T) \
     hipLaunchKernelGGL((k_verify<M, T>), dim3(tiles_grid(n, T)), dim3(kBlock), 0, s, b, ifc, (u32*)d_out)
     if (iface->mode == UNET_MODE_L2) {
-        if (tile <= 16) UNET_LAUNCH_VERIFY(MODE_L2, 16);
-        else if (tile <= 32) UNET_LAUNCH_VERIFY(MODE_L2, 32);
+        if (tile == 16) UNET_LAUNCH_VERIFY(MODE_L2, 16);
+        else if (tile == 32) UNET_LAUNCH_VERIFY(MODE_L2, 32);
         else UNET_LAUNCH_VERIFY(MODE_L2, 64);
     } else {
-        if (tile <= 8) UNET_LAUNCH_VERIFY(MODE_L3, 8);
-        else if (tile <= 16) UNET_LAUNCH_VERIFY(MODE_L3, 16);
-        else if (tile <= 32) UNET_LAUNCH_VERIFY(MODE_L3, 32);
+        if (tile == 16) UNET_LAUNCH_VERIFY(MODE_L3, 16);
+        else if (tile == 32) UNET_LAUNCH_VERIFY(MODE_L3, 32);
         else UNET_LAUNCH_VERIFY(MODE_L3, 64);
     }
 #undef UNET_LAUNCH_VERIFY
@@ -384,7 +392,12 @@ int unet_generate_dev(unet_ctx* ctx, void* stream, uint8_t* d_arena, uint64_t ar
     if (n == 0) return UNET_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
-    hipLaunchKernelGGL(k_generate, dim3(tiles_grid(n)), dim3(kBlock), 0, pick(ctx, stream), b, d_arena, d_status);
+    if (arena_too_small(arena_bytes)) return fail(UNET_E_INVAL, "arena must hold at least 16 bytes");
+    switch (pick_tile(arena_bytes, n)) {
+        case 16: hipLaunchKernelGGL(k_generate<16>, dim3(tiles_grid(n, 16)), dim3(kBlock), 0, pick(ctx, stream), b, d_arena, d_status); break;
+        case 32: hipLaunchKernelGGL(k_generate<32>, dim3(tiles_grid(n, 32)), dim3(kBlock), 0, pick(ctx, stream), b, d_arena, d_status); break;
+        default: hipLaunchKernelGGL(k_generate<64>, dim3(tiles_grid(n, 64)), dim3(kBlock), 0, pick(ctx, stream), b, d_arena, d_status); break;
+    }
     HIP_TRY(hipGetLastError());
     return UNET_OK;
 }
