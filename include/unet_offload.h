@@ -202,6 +202,7 @@ int unet_flow_hash_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint
 #define UNET_SYNTH_IPV4_HDR20 2 /* bare 20-byte headers, stride 20 (use with unet_ipv4_validate) */
 #define UNET_SYNTH_UDP1500 3    /* 1500-byte IPv4+UDP packets, stride16 = 94 */
 #define UNET_SYNTH_IMIX 4       /* mixed 64..9000-byte TCP/UDP/ICMP packets, packed at 16-byte boundaries */
+#define UNET_SYNTH_FLOWS 5      /* IMIX shapes whose 5-tuples come from a table of 2^20 flows of skewed popularity */
 
 /* Length of record idx (bytes) for a trace kind; pure function, host side. */
 uint32_t unet_synth_len(int kind, uint64_t seed, uint64_t idx);
@@ -215,6 +216,21 @@ int unet_synth_host(int kind, uint64_t seed, uint64_t first_idx, uint32_t n, con
 int unet_synth_dev(unet_ctx* ctx, void* stream, int kind, uint64_t seed, uint64_t first_idx, uint32_t n,
                    const unet_iface* iface, const uint32_t* d_off16, const uint32_t* d_len,
                    uint8_t* d_arena, uint64_t arena_bytes);
+
+/* Same as unet_synth_dev for an arbitrary set of trace indices: record r is trace index
+ * first_idx + d_rel_idx[r] (d_rel_idx NULL = r).  d_off16 / d_len describe where each goes. */
+int unet_synth_indexed_dev(unet_ctx* ctx, void* stream, int kind, uint64_t seed, uint64_t first_idx,
+                           const uint32_t* d_rel_idx, uint32_t n, const unet_iface* iface, const uint32_t* d_off16,
+                           const uint32_t* d_len, uint8_t* d_arena, uint64_t arena_bytes);
+/* Lengths of those records (their layout is an exclusive scan of ceil(len/16)). */
+int unet_synth_len_dev(unet_ctx* ctx, void* stream, int kind, uint64_t seed, uint64_t first_idx,
+                       const uint32_t* d_rel_idx, uint32_t n, uint32_t* d_len);
+/* Flow-hash placement of a trace without touching record bytes: d_shard[i] = GPU (0..world-1) that owns
+ * trace index first_idx + i, i.e. unet_flow_hash5 of the record's 5-tuple modulo `world`.
+ * unet_synth_flow_hash is the host-side scalar form of the hash. */
+int unet_synth_shard_dev(unet_ctx* ctx, void* stream, int kind, uint64_t seed, uint64_t first_idx, uint32_t n,
+                         const unet_iface* iface, uint32_t world, uint8_t* d_shard);
+uint32_t unet_synth_flow_hash(int kind, uint64_t seed, uint64_t idx, const unet_iface* iface);
 
 /* ------------------------------------------------------- measurement aid */
 /* Read-only streaming kernel over `bytes` of device memory (16 B per lane, grid-stride):

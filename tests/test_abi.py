@@ -117,3 +117,33 @@ def test_hdr20_trace_verdicts():
     assert {6, 7, 8, 9, 10, 11, 25} <= seen
     idx = np.arange(n)
     assert (res["verdict"][idx % 64 == 27] != 25).all()
+
+
+def test_flow_trace_tuples_match_the_bytes_and_are_skewed():
+    """UNET_SYNTH_FLOWS: the 5-tuple announced by unet_synth_flow_hash is the one in the record's bytes
+    (records whose fault does not touch addressing), and flow popularity is long-tailed."""
+    ifc = unet_amd.Iface(ext_tcp=True)
+    n = 20000
+    for kind in (unet_amd.SYNTH_FLOWS, unet_amd.SYNTH_IMIX, unet_amd.SYNTH_UDP1500):
+        arena, off16, lens = unet_amd.synth_host(kind, SEED, 1000, n, ifc)
+        checked = 0
+        hashes = []
+        for r in range(0, n, 7):
+            idx = 1000 + r
+            h = unet_amd.synth_flow_hash(kind, SEED, idx, ifc)
+            hashes.append(h)
+            if kind != unet_amd.SYNTH_UDP1500 and idx % 64 in (3, 19, 21, 27, 51):
+                continue  # header checksum flip in src, IHL nibble, foreign dst, protocol 47
+            rec = arena[int(off16[r]) * 16:int(off16[r]) * 16 + int(lens[r])].tobytes()
+            assert O.flow_hash_record(rec, ifc) == h, (kind, idx)
+            checked += 1
+        assert checked > 2000
+    # popularity is skewed: 60000 uniform draws from 2^20 flows would leave ~58280 distinct flows
+    ids = {}
+    for idx in range(0, 60000):
+        h = unet_amd.synth_flow_hash(unet_amd.SYNTH_FLOWS, SEED, idx, ifc)
+        ids[h] = ids.get(h, 0) + 1
+    counts = np.sort(np.array(list(ids.values())))[::-1]
+    assert len(ids) < 57600 and counts[0] >= 4
+    res = O.recv_batch(*unet_amd.synth_host(unet_amd.SYNTH_FLOWS, SEED, 0, 4096, ifc), ifc)
+    assert {20, 24, 15, 16} & set(res["verdict"].tolist())

@@ -153,7 +153,7 @@ def test_csum_batch_fixed_stride(offload):
 
 # ------------------------------------------------------------------ synthetic traces: device == host twin, GPU == oracle
 
-@pytest.mark.parametrize("kind,n", [(unet_amd.SYNTH_UDP1500, 3000), (unet_amd.SYNTH_IMIX, 20000)])
+@pytest.mark.parametrize("kind,n", [(unet_amd.SYNTH_UDP1500, 3000), (unet_amd.SYNTH_IMIX, 20000), (unet_amd.SYNTH_FLOWS, 9000)])
 @pytest.mark.parametrize("ext_tcp", [False, True])
 def test_trace_generator_and_verify(offload, kind, n, ext_tcp):
     torch = torch_mod()
@@ -324,6 +324,47 @@ def test_flow_hash_matches_oracle(offload):
     assert (got == exp).all()
 
 
+def test_flow_sharded_generation(offload):
+    """What a rank of a flow-sharded job does: shard ids from the trace definition alone, its own index
+    list, lengths + layout on the device, generation of just those records, verdicts."""
+    torch = torch_mod()
+    ifc = unet_amd.Iface(ext_tcp=True)
+    kind, first, n, world = unet_amd.SYNTH_FLOWS, 5000, 30000, 4
+    d_shard = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    offload.synth_shard_dev(kind, SEED, first, n, ifc, world, d_shard.data_ptr(), stream())
+    torch.cuda.synchronize()
+    shard_h = d_shard.cpu().numpy()
+    exp_shard = np.array([unet_amd.synth_flow_hash(kind, SEED, first + i, ifc) % world for i in range(0, n, 5)])
+    assert (shard_h[::5] == exp_shard).all()
+    sizes = np.bincount(shard_h, minlength=world)
+    assert sizes.min() > 0.8 * n / world and sizes.max() < 1.25 * n / world
+    covered = np.zeros(n, dtype=np.int32)
+    for rank in range(world):
+        rel = torch.nonzero(d_shard == rank).flatten().to(torch.int32)
+        m = rel.numel()
+        d_len = torch.zeros(m, dtype=torch.int32, device="cuda")
+        offload.synth_len_dev(kind, SEED, first, rel.data_ptr(), m, d_len.data_ptr(), stream())
+        torch.cuda.synchronize()
+        slots = (d_len.to(torch.int64) + 15) // 16
+        d_off = (torch.cumsum(slots, 0) - slots).to(torch.int32)
+        nbytes = int(slots.sum().item()) * 16
+        d_arena = torch.full((nbytes,), 0x77, dtype=torch.uint8, device="cuda")
+        offload.synth_indexed_dev(kind, SEED, first, rel.data_ptr(), m, ifc, d_off.data_ptr(), d_len.data_ptr(), d_arena.data_ptr(), nbytes, stream())
+        d_out = torch.zeros(m, dtype=torch.int32, device="cuda")
+        offload.verify_dev(d_arena.data_ptr(), nbytes, d_off.data_ptr(), 0, d_len.data_ptr(), m, ifc, d_out.data_ptr(), stream())
+        torch.cuda.synchronize()
+        rel_h, len_h, off_h, arena_h = rel.cpu().numpy(), d_len.cpu().numpy().astype(np.uint32), d_off.cpu().numpy().astype(np.uint32), d_arena.cpu().numpy()
+        covered[rel_h] += 1
+        # every 50th record of the shard against the host twin, all verdicts against the oracle
+        for k in range(0, m, 50):
+            a1, _, l1 = unet_amd.synth_host(kind, SEED, first + int(rel_h[k]), 1, ifc)
+            assert int(l1[0]) == int(len_h[k])
+            assert (arena_h[int(off_h[k]) * 16:int(off_h[k]) * 16 + int(l1[0])] == a1[:int(l1[0])]).all()
+        exp = O.recv_batch(arena_h, off_h, len_h, ifc)
+        assert (results_to_numpy(d_out) == exp).all()
+    assert (covered == 1).all()
+
+
 # ------------------------------------------------------------------ argument checking
 
 def test_bad_arguments_are_rejected(offload):
@@ -383,6 +424,40 @@ def test_full_size_udp1500_batch_properties(offload):
     assert (d_arena[w0 * stride16 * 16:(w0 + wn) * stride16 * 16].cpu().numpy() == h_arena).all()
     exp = O.recv_batch(h_arena, off16, lens, ifc)
     assert (results_to_numpy(d_out[w0:w0 + wn]) == exp).all()
+
+
+def test_full_size_imix_batch_windows(offload):
+    """8,388,608 mixed 64..9000-byte records generated in HBM (config 4): strict and TCP-extension runs;
+    three host-regenerated windows match the oracle record for record, and the two runs differ exactly
+    on the protocol-6 records."""
+    torch = torch_mod()
+    n = 1 << 23
+    off16, lens, nbytes = unet_amd.synth_layout(unet_amd.SYNTH_IMIX, SEED, 0, n)
+    d_off, d_len = dev(off16), dev(lens)
+    d_arena = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    ifc_t = unet_amd.Iface(ext_tcp=True)
+    offload.synth_dev(unet_amd.SYNTH_IMIX, SEED, 0, n, ifc_t, d_off.data_ptr(), d_len.data_ptr(), d_arena.data_ptr(), nbytes, stream())
+    outs = {}
+    for ext in (True, False):
+        ifc = unet_amd.Iface(ext_tcp=ext)
+        d_out = torch.zeros(n, dtype=torch.int32, device="cuda")
+        offload.verify_dev(d_arena.data_ptr(), nbytes, d_off.data_ptr(), 0, d_len.data_ptr(), n, ifc, d_out.data_ptr(), stream())
+        torch.cuda.synchronize()
+        outs[ext] = d_out
+        for w0 in (0, 4_000_000, n - 20000):
+            wn = 20000
+            h_arena, h_off, h_len = unet_amd.synth_host(unet_amd.SYNTH_IMIX, SEED, w0, wn, ifc)
+            assert (h_len == lens[w0:w0 + wn]).all()
+            b0 = int(off16[w0]) * 16
+            assert (d_arena[b0:b0 + h_arena.nbytes].cpu().numpy() == h_arena).all()
+            exp = O.recv_batch(h_arena, h_off, h_len, ifc)
+            got = results_to_numpy(d_out[w0:w0 + wn])
+            bad = np.nonzero(got != exp)[0]
+            assert bad.size == 0, (ext, w0, bad[:5], got[bad[:5]], exp[bad[:5]])
+    a, b = results_to_numpy(outs[True]), results_to_numpy(outs[False])
+    tcp = a["proto"] == 6
+    assert (b["verdict"][tcp] == Verdict.DROP_L3_PROTO).all() and (a[~tcp] == b[~tcp]).all()
+    assert 0.85 < tcp.mean() < 0.90 and (a["verdict"] != 0).all()
 
 
 def test_full_size_header_batch(offload):

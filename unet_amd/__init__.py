@@ -14,6 +14,7 @@ from ._ffi import (  # noqa: F401
     flow_hash5,
     load_library,
     pack_arena,
+    synth_flow_hash,
     synth_host,
     synth_layout,
     synth_len,
@@ -24,3 +25,4 @@ MODE_L2 = 1
 SYNTH_IPV4_HDR20 = 2
 SYNTH_UDP1500 = 3
 SYNTH_IMIX = 4
+SYNTH_FLOWS = 5

@@ -125,6 +125,10 @@ _SIGS = {
     "unet_synth_layout": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, _u32p, _u32p, C.POINTER(C.c_uint64)]),
     "unet_synth_host": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(_IfaceC), _u32p, _u32p, _u8p, C.c_uint64]),
     "unet_synth_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(_IfaceC), _u32p, _u32p, _u8p, C.c_uint64]),
+    "unet_synth_indexed_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_uint64, C.c_uint64, _u32p, C.c_uint32, C.POINTER(_IfaceC), _u32p, _u32p, _u8p, C.c_uint64]),
+    "unet_synth_len_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_uint64, C.c_uint64, _u32p, C.c_uint32, _u32p]),
+    "unet_synth_shard_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(_IfaceC), C.c_uint32, _u8p]),
+    "unet_synth_flow_hash": (C.c_uint32, [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(_IfaceC)]),
     "unet_stream_read_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p]),
 }
 
@@ -209,6 +213,12 @@ def synth_host(kind: int, seed: int, first_idx: int, n: int, iface: Iface):
     _check(load_library().unet_synth_host(kind, seed, first_idx, n, C.byref(ic), _np_ptr(off16), _np_ptr(lens),
                                           _np_ptr(arena), nbytes))
     return arena, off16, lens
+
+
+def synth_flow_hash(kind: int, seed: int, idx: int, iface: Iface) -> int:
+    """Flow hash of the 5-tuple that record `idx` of the trace carries (before fault injection)."""
+    ic = iface.c()
+    return int(load_library().unet_synth_flow_hash(kind, seed, idx, C.byref(ic)))
 
 
 def flow_hash5(src: int, dst: int, proto: int, sport: int, dport: int) -> int:
@@ -324,6 +334,17 @@ class Offload:
     def synth_dev(self, kind, seed, first_idx, n, iface: Iface, d_off16, d_len, d_arena, arena_bytes, stream=None):
         ic = iface.c()
         _check(self.lib.unet_synth_dev(self.h, stream, kind, seed, first_idx, n, C.byref(ic), d_off16, d_len, d_arena, arena_bytes))
+
+    def synth_indexed_dev(self, kind, seed, first_idx, d_rel_idx, n, iface: Iface, d_off16, d_len, d_arena, arena_bytes, stream=None):
+        ic = iface.c()
+        _check(self.lib.unet_synth_indexed_dev(self.h, stream, kind, seed, first_idx, d_rel_idx, n, C.byref(ic), d_off16, d_len, d_arena, arena_bytes))
+
+    def synth_len_dev(self, kind, seed, first_idx, d_rel_idx, n, d_len, stream=None):
+        _check(self.lib.unet_synth_len_dev(self.h, stream, kind, seed, first_idx, d_rel_idx, n, d_len))
+
+    def synth_shard_dev(self, kind, seed, first_idx, n, iface: Iface, world, d_shard, stream=None):
+        ic = iface.c()
+        _check(self.lib.unet_synth_shard_dev(self.h, stream, kind, seed, first_idx, n, C.byref(ic), world, d_shard))
 
     def stream_read_dev(self, d_buf, nbytes, d_sink, stream=None):
         _check(self.lib.unet_stream_read_dev(self.h, stream, d_buf, nbytes, d_sink))

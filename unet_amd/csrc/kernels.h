@@ -476,18 +476,23 @@ __global__ __launch_bounds__(kBlock) void k_stream_read(const u32x4* __restrict_
 }
 
 // ------------------------------------------------------------------ synthetic traces
+// Record r of a generated batch is trace index first_idx + (rel_idx ? rel_idx[r] : r).
+__device__ __forceinline__ u64 trace_index(u64 first_idx, const u32* __restrict__ rel_idx, u32 r) {
+    return first_idx + (rel_idx ? (u64)rel_idx[r] : (u64)r);
+}
+
 // Layer 1 (+ the post-checksum payload flip): one wave per record, 16 bytes per lane.
-__global__ __launch_bounds__(kBlock) void k_synth_raw(int kind, u64 seed, u64 first_idx, u32 n,
-                                                      const u32* __restrict__ off16, u32 stride16,
+__global__ __launch_bounds__(kBlock) void k_synth_raw(int kind, u64 seed, u64 first_idx, const u32* __restrict__ rel_idx,
+                                                      u32 n, const u32* __restrict__ off16,
                                                       const u32* __restrict__ len, uint8_t* __restrict__ arena) {
     const u32 lane = threadIdx.x & 63u;
     const u32 rec = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
     if (rec >= n) return;
-    const u64 idx = first_idx + rec;
+    const u64 idx = trace_index(first_idx, rel_idx, rec);
     const u64 key = unetsynth::key_of(seed, idx);
     const unetsynth::Shape s = unetsynth::shape_of(kind, seed, idx);
     const u32 flen = len[rec];
-    const u64 slot = off16 ? off16[rec] : (u64)rec * stride16;
+    const u64 slot = off16[rec];
     u32 fpos = 0, fmask = 0;
     const bool has_flip = unetsynth::flip_of(kind, key, s, &fpos, &fmask);
     u64* dst = reinterpret_cast<u64*>(arena + slot * 16u);
@@ -504,22 +509,43 @@ __global__ __launch_bounds__(kBlock) void k_synth_raw(int kind, u64 seed, u64 fi
 }
 
 // Layer 2: one lane per record builds the headers (with their checksums) and stores them.
-__global__ __launch_bounds__(kBlock) void k_synth_hdr(int kind, u64 seed, u64 first_idx, u32 n, u32 unicast,
-                                                      u32 broadcast, const u32* __restrict__ off16, u32 stride16,
-                                                      uint8_t* __restrict__ arena) {
+__global__ __launch_bounds__(kBlock) void k_synth_hdr(int kind, u64 seed, u64 first_idx, const u32* __restrict__ rel_idx,
+                                                      u32 n, u32 unicast, u32 broadcast,
+                                                      const u32* __restrict__ off16, uint8_t* __restrict__ arena) {
     const u32 rec = blockIdx.x * kBlock + threadIdx.x;
     if (rec >= n) return;
-    const u64 idx = first_idx + rec;
+    const u64 idx = trace_index(first_idx, rel_idx, rec);
     const u64 key = unetsynth::key_of(seed, idx);
     const unetsynth::Shape s = unetsynth::shape_of(kind, seed, idx);
+    const unetsynth::Tuple tp = unetsynth::tuple_of(kind, seed, idx, s, unicast, broadcast);
     uint8_t h[96];
-    const u32 hb = unetsynth::build_header(kind, key, s, unicast, broadcast, h);
-    uint8_t* base = kind == unetsynth::kKindHdr20 ? arena + (u64)rec * 20u
-                                                  : arena + (off16 ? (u64)off16[rec] : (u64)rec * stride16) * 16u;
+    const u32 hb = unetsynth::build_header(kind, key, s, tp, unicast, h);
+    uint8_t* base = kind == unetsynth::kKindHdr20 ? arena + (u64)rec * 20u : arena + (u64)off16[rec] * 16u;
     u32* dst = reinterpret_cast<u32*>(base);
     for (u32 i = 0; i < hb; i += 4) {
         dst[i >> 2] = (u32)h[i] | ((u32)h[i + 1] << 8) | ((u32)h[i + 2] << 16) | ((u32)h[i + 3] << 24);
     }
+}
+
+// Record lengths of a set of trace indices (the layout is an exclusive scan of their 16-byte slots).
+__global__ __launch_bounds__(kBlock) void k_synth_len(int kind, u64 seed, u64 first_idx, const u32* __restrict__ rel_idx,
+                                                      u32 n, u32* __restrict__ len) {
+    const u32 rec = blockIdx.x * kBlock + threadIdx.x;
+    if (rec >= n) return;
+    len[rec] = unetsynth::shape_of(kind, seed, trace_index(first_idx, rel_idx, rec)).len;
+}
+
+// GPU that owns each trace index of [first_idx, first_idx + n): flow hash of the record's 5-tuple
+// modulo the number of GPUs.  Needs no record bytes, so a rank can pick its records before it
+// generates (or receives) any of them.
+__global__ __launch_bounds__(kBlock) void k_synth_shard(int kind, u64 seed, u64 first_idx, u32 n, u32 unicast,
+                                                        u32 broadcast, u32 world, uint8_t* __restrict__ shard) {
+    const u32 rec = blockIdx.x * kBlock + threadIdx.x;
+    if (rec >= n) return;
+    const u64 idx = first_idx + rec;
+    const unetsynth::Shape s = unetsynth::shape_of(kind, seed, idx);
+    const unetsynth::Tuple tp = unetsynth::tuple_of(kind, seed, idx, s, unicast, broadcast);
+    shard[rec] = (uint8_t)(flow_hash5(tp.src, tp.dst, tp.proto, tp.sport, tp.dport) % world);
 }
 
 }  // namespace unetdev

@@ -31,6 +31,8 @@ constexpr u64 kGolden = 0x9E3779B97F4A7C15ull;
 constexpr int kKindHdr20 = 2;
 constexpr int kKindUdp1500 = 3;
 constexpr int kKindImix = 4;
+constexpr int kKindFlows = 5;  // IMIX shapes, but the 5-tuple comes from a table of 2^20 flows (skewed popularity)
+constexpr u32 kFlowCount = 1u << 20;
 
 UNET_HD u64 fin(u64 z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -68,6 +70,24 @@ constexpr u32 kFaultIhlOpt = 59;     // HDR20: IHL 6..14 (valid: only 20 bytes a
 constexpr u32 kFault256UdpLen = 33;  // UDP1500: length field short by 8..32
 constexpr u32 kFault256Csum0 = 97;   // UDP1500: transmitted checksum 0x0000
 
+// The addressing 5-tuple a record carries before any fault is applied (ports are 0 for ICMP).
+struct Tuple {
+    u32 src, dst, proto, sport, dport;
+};
+
+// kKindFlows: flow popularity is the product of two uniform 20-bit draws (a long-tailed, Zipf-like
+// law: half of all records fall on ~19 % of the flows, 10 % of them on ~0.7 %).
+UNET_HD u32 flow_id_of(u64 key) {
+    const u64 f = field(key, 15);
+    const u64 a = (f >> 44) & 0xfffff, b = (f >> 24) & 0xfffff;
+    return (u32)((a * b) >> 20);
+}
+UNET_HD u64 flow_key(u64 seed, u32 flow) { return fin((seed ^ 0xF10F10F10F10F10Full) + (u64)(flow + 1) * kGolden); }
+UNET_HD u32 flow_proto(u64 fk) {
+    const u32 b = (u32)((fin(fk) >> 8) % 100);
+    return b < 88 ? 6u : (b < 98 ? 17u : 1u);
+}
+
 UNET_HD Shape shape_of(int kind, u64 seed, u64 idx) {
     Shape s;
     u64 key = key_of(seed, idx);
@@ -90,11 +110,35 @@ UNET_HD Shape shape_of(int kind, u64 seed, u64 idx) {
         s.len = a < 56 ? 64u : (a < 88 ? 576u : (a < 96 ? 1500u : (a < 98 ? 4096u : 9000u)));
         u32 b = (u32)((f6 >> 8) % 100);
         s.proto = b < 88 ? 6u : (b < 98 ? 17u : 1u);
+        if (kind == kKindFlows) s.proto = flow_proto(flow_key(seed, flow_id_of(key)));
         if (((f6 >> 16) % 20) == 0) s.ihl = ((f6 >> 24) & 1) ? 8u : 6u;
         s.l4hl = s.proto == 6 ? ((((f6 >> 32) % 8) == 0) ? 32u : 20u) : 8u;
     }
     s.payload_start = s.ihl * 4 + s.l4hl;
     return s;
+}
+
+UNET_HD Tuple tuple_of(int kind, u64 seed, u64 idx, const Shape& s, u32 unicast, u32 broadcast) {
+    const u64 key = key_of(seed, idx);
+    Tuple t;
+    u64 ports, dsel_src;
+    if (kind == kKindFlows) {
+        const u64 fk = flow_key(seed, flow_id_of(key));
+        t.src = (u32)fk;
+        ports = fk >> 32;
+        dsel_src = fin(fk) >> 32;
+    } else {
+        t.src = (u32)field(key, 1);
+        ports = field(key, 3);
+        dsel_src = field(key, 2);
+    }
+    const u32 dsel = (u32)(dsel_src % 16);
+    t.dst = dsel == 0 ? broadcast : (dsel == 1 ? 0xffffffffu : unicast);
+    t.proto = s.proto;
+    const bool has_ports = s.proto == 17 || s.proto == 6;
+    t.sport = has_ports ? (u32)ports & 0xffff : 0u;
+    t.dport = has_ports ? (u32)(ports >> 16) & 0xffff : 0u;
+    return t;
 }
 
 // Position and mask of the post-checksum payload bit flip, if this record has one.
@@ -147,16 +191,15 @@ UNET_HD u32 fold_not(u32 s) {
 
 // Writes header bytes [0, s.payload_start) of record idx into h (at least 96 bytes) and
 // returns payload_start.  For kKindHdr20 writes the 20 header bytes.
-UNET_HD u32 build_header(int kind, u64 key, const Shape& s, u32 unicast, u32 broadcast, uint8_t* h) {
-    const u64 f0 = field(key, 0), f1 = field(key, 1), f2 = field(key, 2), f3 = field(key, 3);
+UNET_HD u32 build_header(int kind, u64 key, const Shape& s, const Tuple& tp, u32 unicast, uint8_t* h) {
+    const u64 f0 = field(key, 0), f3 = field(key, 3);
     const u64 f4 = field(key, 4), f5 = field(key, 5), f7 = field(key, 7), f8 = field(key, 8);
     const u32 hl = s.ihl * 4;
-    const bool imix = kind == kKindImix;
+    const bool imix = kind == kKindImix || kind == kKindFlows;
     // ---- IPv4 header
     u32 ihl_nibble = s.ihl, version = 4, proto = s.proto;
     u32 flags_frag = ((f0 >> 24) & 1) ? 0x4000u : 0u;
-    u32 dsel = (u32)(f2 % 16);
-    u32 dst = dsel == 0 ? broadcast : (dsel == 1 ? 0xffffffffu : unicast);
+    u32 dst = tp.dst;
     if (kind != kKindUdp1500) {
         if (s.fault == kFaultVersion) version = 6;
         if (s.fault == kFaultIhlShort) ihl_nibble = 4;
@@ -176,7 +219,7 @@ UNET_HD u32 build_header(int kind, u64 key, const Shape& s, u32 unicast, u32 bro
     h[9] = (uint8_t)proto;
     h[10] = 0;
     h[11] = 0;
-    put32(h + 12, (u32)f1);
+    put32(h + 12, tp.src);
     put32(h + 16, dst);
     for (u32 i = 20; i < hl; i++) h[i] = (uint8_t)(field(key, 12 + (i >> 3)) >> (8 * (i & 7)));
     put16(h + 10, fold_not(sum_be_even(h, 20)));  // options are not part of the sum (ipv4.rs:159-182)
@@ -193,14 +236,14 @@ UNET_HD u32 build_header(int kind, u64 key, const Shape& s, u32 unicast, u32 bro
         u32 length = seglen;
         if (kind == kKindUdp1500 && s.fault256 == kFault256UdpLen) length -= 8 * (1 + (u32)(f4 % 4));
         if (imix && s.fault == kFaultUdpLen) length -= 4;
-        put16(l4, (u32)f3 & 0xffff);
-        put16(l4 + 2, (u32)(f3 >> 16) & 0xffff);
+        put16(l4, tp.sport);
+        put16(l4 + 2, tp.dport);
         put16(l4 + 4, length);
         csum_off = 6;
-        pseudo = ((u32)f1 >> 16) + ((u32)f1 & 0xffff) + (dst >> 16) + (dst & 0xffff) + 17 + length;
+        pseudo = (tp.src >> 16) + (tp.src & 0xffff) + (dst >> 16) + (dst & 0xffff) + 17 + length;
     } else if (s.proto == 6) {
-        put16(l4, (u32)f3 & 0xffff);
-        put16(l4 + 2, (u32)(f3 >> 16) & 0xffff);
+        put16(l4, tp.sport);
+        put16(l4 + 2, tp.dport);
         put32(l4 + 4, (u32)f7);
         put32(l4 + 8, (u32)(f7 >> 32));
         l4[12] = (uint8_t)((s.l4hl / 4) << 4);
@@ -209,7 +252,7 @@ UNET_HD u32 build_header(int kind, u64 key, const Shape& s, u32 unicast, u32 bro
         put16(l4 + 18, 0);
         for (u32 i = 20; i < s.l4hl; i++) l4[i] = (uint8_t)(field(key, 9 + (i >> 3)) >> (8 * (i & 7)));
         csum_off = 16;
-        pseudo = ((u32)f1 >> 16) + ((u32)f1 & 0xffff) + (dst >> 16) + (dst & 0xffff) + 6 + seglen;
+        pseudo = (tp.src >> 16) + (tp.src & 0xffff) + (dst >> 16) + (dst & 0xffff) + 6 + seglen;
     } else {
         u32 type = (f3 & 1) ? 8u : 0u;
         if (imix && s.fault == kFaultIcmpType) type = 3;

@@ -461,12 +461,19 @@ int unet_flow_hash_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint
 /* ---------------------------------------------------------------- synthetic traces */
 
 static bool kind_ok(int kind) {
-    return kind == UNET_SYNTH_IPV4_HDR20 || kind == UNET_SYNTH_UDP1500 || kind == UNET_SYNTH_IMIX;
+    return kind == UNET_SYNTH_IPV4_HDR20 || kind == UNET_SYNTH_UDP1500 || kind == UNET_SYNTH_IMIX || kind == UNET_SYNTH_FLOWS;
 }
 
 uint32_t unet_synth_len(int kind, uint64_t seed, uint64_t idx) {
     if (!kind_ok(kind)) return 0;
     return unetsynth::shape_of(kind, seed, idx).len;
+}
+
+uint32_t unet_synth_flow_hash(int kind, uint64_t seed, uint64_t idx, const unet_iface* iface) {
+    if (!kind_ok(kind) || !iface) return 0;
+    const unetsynth::Shape s = unetsynth::shape_of(kind, seed, idx);
+    const unetsynth::Tuple tp = unetsynth::tuple_of(kind, seed, idx, s, iface->unicast, iface->broadcast);
+    return flow_hash5(tp.src, tp.dst, tp.proto, tp.sport, tp.dport);
 }
 
 int unet_synth_layout(int kind, uint64_t seed, uint64_t first_idx, uint32_t n, uint32_t* off16, uint32_t* len,
@@ -498,10 +505,11 @@ int unet_synth_host(int kind, uint64_t seed, uint64_t first_idx, uint32_t n, con
         const u64 idx = first_idx + r;
         const u64 key = unetsynth::key_of(seed, idx);
         const unetsynth::Shape s = unetsynth::shape_of(kind, seed, idx);
+        const unetsynth::Tuple tp = unetsynth::tuple_of(kind, seed, idx, s, iface->unicast, iface->broadcast);
         uint8_t h[96];
         if (kind == UNET_SYNTH_IPV4_HDR20) {
             if ((u64)r * 20u + 20u > arena_bytes) return fail(UNET_E_RANGE, "arena too small");
-            unetsynth::build_header(kind, key, s, iface->unicast, iface->broadcast, h);
+            unetsynth::build_header(kind, key, s, tp, iface->unicast, h);
             memcpy(arena + (u64)r * 20u, h, 20);
             continue;
         }
@@ -513,7 +521,7 @@ int unet_synth_host(int kind, uint64_t seed, uint64_t first_idx, uint32_t n, con
             const u64 w = unetsynth::raw_word(key, k);
             memcpy(rec + 8u * k, &w, 8);  // little-endian host
         }
-        const u32 hb = unetsynth::build_header(kind, key, s, iface->unicast, iface->broadcast, h);
+        const u32 hb = unetsynth::build_header(kind, key, s, tp, iface->unicast, h);
         memcpy(rec, h, hb);
         u32 fpos, fmask;
         if (unetsynth::flip_of(kind, key, s, &fpos, &fmask)) rec[fpos] ^= (uint8_t)fmask;
@@ -521,9 +529,9 @@ int unet_synth_host(int kind, uint64_t seed, uint64_t first_idx, uint32_t n, con
     return UNET_OK;
 }
 
-int unet_synth_dev(unet_ctx* ctx, void* stream, int kind, uint64_t seed, uint64_t first_idx, uint32_t n,
-                   const unet_iface* iface, const uint32_t* d_off16, const uint32_t* d_len, uint8_t* d_arena,
-                   uint64_t arena_bytes) {
+int unet_synth_indexed_dev(unet_ctx* ctx, void* stream, int kind, uint64_t seed, uint64_t first_idx,
+                           const uint32_t* d_rel_idx, uint32_t n, const unet_iface* iface, const uint32_t* d_off16,
+                           const uint32_t* d_len, uint8_t* d_arena, uint64_t arena_bytes) {
     if (!ctx) return fail(UNET_E_INVAL, "null context");
     if (!kind_ok(kind)) return fail(UNET_E_INVAL, "unknown trace kind %d", kind);
     if (n == 0) return UNET_OK;
@@ -534,11 +542,44 @@ int unet_synth_dev(unet_ctx* ctx, void* stream, int kind, uint64_t seed, uint64_
     hipStream_t s = pick(ctx, stream);
     if (kind != UNET_SYNTH_IPV4_HDR20) {
         const u32 grid = (n + (kBlock / kWave) - 1) / (kBlock / kWave);
-        hipLaunchKernelGGL(k_synth_raw, dim3(grid), dim3(kBlock), 0, s, kind, seed, first_idx, n, d_off16, 0u, d_len, d_arena);
+        hipLaunchKernelGGL(k_synth_raw, dim3(grid), dim3(kBlock), 0, s, kind, seed, first_idx, d_rel_idx, n, d_off16, d_len, d_arena);
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_synth_hdr, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, kind, seed, first_idx, n,
-                       iface->unicast, iface->broadcast, d_off16, 0u, d_arena);
+    hipLaunchKernelGGL(k_synth_hdr, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, kind, seed, first_idx, d_rel_idx, n,
+                       iface->unicast, iface->broadcast, d_off16, d_arena);
+    HIP_TRY(hipGetLastError());
+    return UNET_OK;
+}
+
+int unet_synth_dev(unet_ctx* ctx, void* stream, int kind, uint64_t seed, uint64_t first_idx, uint32_t n,
+                   const unet_iface* iface, const uint32_t* d_off16, const uint32_t* d_len, uint8_t* d_arena,
+                   uint64_t arena_bytes) {
+    return unet_synth_indexed_dev(ctx, stream, kind, seed, first_idx, nullptr, n, iface, d_off16, d_len, d_arena, arena_bytes);
+}
+
+int unet_synth_len_dev(unet_ctx* ctx, void* stream, int kind, uint64_t seed, uint64_t first_idx,
+                       const uint32_t* d_rel_idx, uint32_t n, uint32_t* d_len) {
+    if (!ctx) return fail(UNET_E_INVAL, "null context");
+    if (!kind_ok(kind)) return fail(UNET_E_INVAL, "unknown trace kind %d", kind);
+    if (n == 0) return UNET_OK;
+    if (!d_len) return fail(UNET_E_INVAL, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_synth_len, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, pick(ctx, stream), kind, seed, first_idx,
+                       d_rel_idx, n, d_len);
+    HIP_TRY(hipGetLastError());
+    return UNET_OK;
+}
+
+int unet_synth_shard_dev(unet_ctx* ctx, void* stream, int kind, uint64_t seed, uint64_t first_idx, uint32_t n,
+                         const unet_iface* iface, uint32_t world, uint8_t* d_shard) {
+    if (!ctx) return fail(UNET_E_INVAL, "null context");
+    if (!kind_ok(kind)) return fail(UNET_E_INVAL, "unknown trace kind %d", kind);
+    if (n == 0) return UNET_OK;
+    if (!iface || !d_shard) return fail(UNET_E_INVAL, "null argument");
+    if (world == 0 || world > 255) return fail(UNET_E_INVAL, "world size %u outside 1..255", world);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_synth_shard, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, pick(ctx, stream), kind, seed, first_idx, n,
+                       iface->unicast, iface->broadcast, world, d_shard);
     HIP_TRY(hipGetLastError());
     return UNET_OK;
 }
