@@ -1,13 +1,21 @@
 #!/usr/bin/env python3
-"""Headline benchmark: receive-path verdicts (IPv4 validate + UDP pseudo-header checksum) over
-4,194,304 synthetic 1500-byte packets per GPU, resident in HBM.
+"""Benchmark of the offloaded receive path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W                    # headline: udp1500
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one launch of the verify kernel over the rank's whole batch.  Ranks hold disjoint index
-ranges of the same trace (weak scaling); nothing crosses GPUs on the data path, only the per-verdict
-counters are all-reduced (RCCL) after the timed region.  Rank 0 prints one JSON line.
+Workloads (BASELINE.json configs):
+  udp1500  4,194,304 x 1500-byte IPv4/UDP packets per GPU          (configs[2], the headline metric)
+  imix     8,388,608 mixed 64..9000-byte TCP/UDP/ICMP packets      (configs[3])
+  hdr20    16,777,216 bare 20-byte IPv4 headers                    (configs[1])
+  trace    a long flow-table trace generated chunk by chunk in HBM (configs[4]; --total-frames)
+
+One "step" = one launch of the kernel over the rank's whole resident batch.  With N > 1 the global batch
+is N times larger and every rank takes the records whose 5-tuple flow hash % N is its rank (computed
+from the trace definition, before any record exists), so a flow stays on one GPU and nothing crosses
+GPUs on the data path; only the 32 per-verdict counters are all-reduced (RCCL) after the timed region.
+Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -29,10 +37,17 @@ SEED = 0x756E6574
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
 
 WORKLOADS = {
-    # name: (trace kind, frames per GPU, fixed stride in 16-byte slots or 0)
+    # name: (trace kind, records per GPU per batch, fixed stride in 16-byte slots or 0)
     "udp1500": (unet_amd.SYNTH_UDP1500, 1 << 22, 94),
     "imix": (unet_amd.SYNTH_IMIX, 1 << 23, 0),
     "hdr20": (unet_amd.SYNTH_IPV4_HDR20, 1 << 24, 0),
+    "trace": (unet_amd.SYNTH_FLOWS, 1 << 24, 0),
+}
+DESCRIPTION = {
+    "udp1500": "4,194,304 x 1500-byte IPv4/UDP packets per GPU (BASELINE configs[2])",
+    "imix": "8,388,608 mixed 64-9000-byte TCP/UDP/ICMP packets per GPU (BASELINE configs[3])",
+    "hdr20": "16,777,216 bare 20-byte IPv4 headers per GPU (BASELINE configs[1])",
+    "trace": "flow-table trace (2^20 flows, IMIX sizes) generated in HBM in chunks of 16,777,216 records per GPU (BASELINE configs[4])",
 }
 
 
@@ -59,16 +74,77 @@ def cpu_baseline(kind, ifc, budget_s):
             "sample": f"{n} records of the same trace x {passes} passes ({dt:.1f} s, oracle/unet_oracle.c, gcc -O2, 1 thread)"}
 
 
+class Batch:
+    """One resident batch of a rank: arena + tables + result buffer in HBM."""
+
+    def __init__(self, ctx, stream, kind, ifc, first_idx, n_global, world, rank, stride16):
+        self.kind, self.ifc, self.ctx, self.stream = kind, ifc, ctx, stream
+        self.rel = None
+        if kind == unet_amd.SYNTH_IPV4_HDR20:
+            # bare headers carry no usable flow state: ranks take index ranges
+            per = n_global // world
+            self.first, self.n = first_idx + rank * per, per
+            self.nbytes = (self.n * 20 + 15) // 16 * 16
+            self.arena = torch.empty(self.nbytes + 16, dtype=torch.uint8, device="cuda")
+            ctx.synth_dev(kind, SEED, self.first, self.n, ifc, None, None, self.arena.data_ptr(), self.nbytes, stream)
+            self.off = self.len = None
+            self.alg_bytes = self.n * 24  # 20 read + 4 written per header
+            self.stride16 = 0
+        else:
+            self.first = first_idx
+            if world == 1:
+                self.n, rel_ptr = n_global, None
+            else:
+                d_shard = torch.empty(n_global, dtype=torch.uint8, device="cuda")
+                ctx.synth_shard_dev(kind, SEED, first_idx, n_global, ifc, world, d_shard.data_ptr(), stream)
+                self.rel = torch.nonzero(d_shard == rank).flatten().to(torch.int32)
+                del d_shard
+                self.n, rel_ptr = self.rel.numel(), self.rel.data_ptr()
+            # lengths from the trace definition, layout = exclusive scan of the 16-byte slot counts
+            self.len = torch.empty(self.n, dtype=torch.int32, device="cuda")
+            ctx.synth_len_dev(kind, SEED, first_idx, rel_ptr, self.n, self.len.data_ptr(), stream)
+            slots = (self.len.to(torch.int64) + 15) // 16
+            self.off = (torch.cumsum(slots, 0) - slots).to(torch.int32)
+            self.nbytes = int(slots.sum().item()) * 16
+            self.arena = torch.empty(self.nbytes + 16, dtype=torch.uint8, device="cuda")
+            ctx.synth_indexed_dev(kind, SEED, first_idx, rel_ptr, self.n, ifc, self.off.data_ptr(), self.len.data_ptr(),
+                                  self.arena.data_ptr(), self.nbytes, stream)
+            self.alg_bytes = int(self.len.to(torch.int64).sum().item()) + 8 * self.n  # bytes + 4 (length) + 4 (result)
+            self.stride16 = stride16
+        self.out = torch.zeros(self.n, dtype=torch.int32, device="cuda")
+
+    def run(self):
+        if self.kind == unet_amd.SYNTH_IPV4_HDR20:
+            self.ctx.ipv4_validate_dev(self.arena.data_ptr(), self.n, self.ifc, self.out.data_ptr(), self.stream)
+        else:
+            off_ptr = None if self.stride16 else self.off.data_ptr()
+            self.ctx.verify_dev(self.arena.data_ptr(), self.nbytes, off_ptr, self.stride16, self.len.data_ptr(), self.n,
+                                self.ifc, self.out.data_ptr(), self.stream)
+
+    def counts(self):
+        d_cnt = torch.zeros(32, dtype=torch.int64, device="cuda")
+        self.ctx.count_verdicts_dev(self.out.data_ptr(), self.n, d_cnt.data_ptr(), self.stream)
+        return d_cnt
+
+    def trace_indices(self):
+        if self.rel is None:
+            return np.arange(self.first, self.first + self.n, dtype=np.int64)
+        return self.first + self.rel.cpu().numpy().astype(np.int64)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="udp1500", choices=sorted(WORKLOADS))
-    ap.add_argument("--ext-tcp", type=int, default=None, help="TCP extension on/off (default: on for imix only)")
+    ap.add_argument("--ext-tcp", type=int, default=None, help="TCP extension on/off (default: on for imix/trace)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (0 = skip)")
-    ap.add_argument("--frames", type=int, default=0, help="override frames per GPU")
-    ap.add_argument("--rotate", type=int, default=0, help="number of distinct batches cycled through (default: 6 for hdr20, else 1)")
+    ap.add_argument("--frames", type=int, default=0, help="override records per GPU per batch")
+    ap.add_argument("--rotate", type=int, default=0, help="distinct resident batches cycled through (default 6 for hdr20, else 1)")
+    ap.add_argument("--total-frames", type=int, default=1 << 30, help="trace workload: records in the whole trace (all GPUs)")
+    ap.add_argument("--emulate-world", type=int, default=0, help="single-GPU rehearsal of the sharded path: pretend to be one of W ranks")
+    ap.add_argument("--emulate-rank", type=int, default=0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -83,11 +159,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    shard_world, shard_rank = (args.emulate_world, args.emulate_rank) if args.emulate_world else (world, rank)
 
-    kind, n, stride16 = WORKLOADS[args.workload]
+    kind, n_per_gpu, stride16 = WORKLOADS[args.workload]
     if args.frames:
-        n = args.frames
-    ext_tcp = (args.workload == "imix") if args.ext_tcp is None else bool(args.ext_tcp)
+        n_per_gpu = args.frames
+    ext_tcp = (args.workload in ("imix", "trace")) if args.ext_tcp is None else bool(args.ext_tcp)
     ifc = unet_amd.Iface(ext_tcp=ext_tcp)
     ctx = unet_amd.Offload(local)
     # A dedicated torch stream: its raw handle goes to the C ABI, so the kernels, torch's own ops and the
@@ -96,108 +173,157 @@ def main():
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     assert stream, "need a non-null stream handle (NULL selects the library's private stream)"
-    first_idx, n = shard.rank_index_range(rank, world, n)
+    n_global = n_per_gpu * shard_world  # records per global batch
 
-    # ---- build the batch(es) in HBM.  A workload whose arena is not far larger than the 256 MiB Infinity
-    # Cache is rotated over several distinct batches (consecutive index ranges of the same trace) so that
-    # no launch finds its input in cache.
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.workload == "trace":
+        # ---- config 5: the trace does not fit in HBM, so it is generated, judged and dropped chunk by
+        # chunk; only the verify launches are timed (inputs resident when each timed region starts).
+        n_chunks = min(args.steps, max(1, args.total_frames // n_global))
+        kernel_s, frames, alg_bytes_total = 0.0, 0, 0
+        total_cnt = torch.zeros(32, dtype=torch.int64, device="cuda")
+        sizes = []
+        sync_all()
+        t_all = time.perf_counter()
+        for c in range(n_chunks):
+            b = Batch(ctx, stream, kind, ifc, c * n_global, n_global, shard_world, shard_rank, 0)
+            if c == 0:
+                b.run()  # warm the code path once
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            b.run()
+            e1.record()
+            torch.cuda.synchronize()
+            kernel_s += e0.elapsed_time(e1) * 1e-3
+            total_cnt += b.counts()
+            frames += b.n
+            alg_bytes_total += b.alg_bytes
+            sizes.append(b.n)
+            del b
+        sync_all()
+        wall_all = time.perf_counter() - t_all
+        kernel_s_max = shard.max_over_ranks(kernel_s, "cuda", dist)
+        frames_t = torch.tensor([frames, alg_bytes_total], dtype=torch.int64, device="cuda")
+        if dist:
+            dist.all_reduce(frames_t)
+        frames_all, bytes_all = int(frames_t[0].item()), int(frames_t[1].item())
+        cnt = shard.allreduce_counts(total_cnt, dist).cpu().numpy()
+        if rank == 0:
+            achieved = alg_bytes_total / kernel_s / 1e9
+            line = {
+                "metric": "Gpkt/s and achieved HBM GB/s, batched IPv4+TCP/UDP checksum+parse, 1500B",
+                "value": frames_all / kernel_s_max / 1e9, "unit": "Gpkt/s", "n_gpus": world, "steps": n_chunks, "warmup": 0,
+                "ms_per_step": kernel_s_max * 1e3 / n_chunks, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "u32", "data": "synthetic",
+                "config": {"workload": DESCRIPTION["trace"], "records_judged": frames_all, "chunks": n_chunks,
+                           "ext_tcp": ext_tcp, "shard_world": shard_world, "shard_rank": shard_rank,
+                           "rank0_shard_sizes_min_max": [min(sizes), max(sizes)],
+                           "rank0_shard_skew_vs_even": max(sizes) / n_per_gpu,
+                           "timing": "sum of HIP-event times around the verify launches (max over ranks); generation excluded",
+                           "end_to_end_Gpkt_s_incl_generation": frames_all / wall_all / 1e9},
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": "k_verify<MODE_L3>",
+                             "kernel_ms": kernel_s * 1e3 / n_chunks, "algorithmic_bytes_per_launch": alg_bytes_total // n_chunks},
+                "hbm_GBps_all_gpus": bytes_all / kernel_s_max / 1e9,
+                "verdict_counts": {Verdict(i).name: int(c) for i, c in enumerate(cnt) if c},
+            }
+            if world == 1 and args.cpu_seconds > 0:
+                line["cpu_baseline"] = cpu_baseline(kind, ifc, args.cpu_seconds)
+            print(json.dumps(line), flush=True)
+        ctx.close()
+        if dist:
+            dist.destroy_process_group()
+        return
+
+    # ---- resident batches.  A workload whose arena is not far larger than the 256 MiB Infinity Cache is
+    # rotated over several distinct batches (consecutive index ranges of the same trace) so that no
+    # launch finds its input in cache.
     rotate = args.rotate if args.rotate else (6 if kind == unet_amd.SYNTH_IPV4_HDR20 else 1)
-    steps_fns, keep = [], []
-    for r in range(rotate):
-        f_idx = first_idx + r * world * n
-        off16, lens, nbytes = unet_amd.synth_layout(kind, SEED, f_idx, n)
-        d_arena = torch.empty(nbytes + 16, dtype=torch.uint8, device="cuda")
-        d_out = torch.zeros(n, dtype=torch.int32, device="cuda")
-        if kind == unet_amd.SYNTH_IPV4_HDR20:
-            ctx.synth_dev(kind, SEED, f_idx, n, ifc, None, None, d_arena.data_ptr(), nbytes, stream)
-            alg_bytes = n * 24  # 20 read + 4 written per header
-            fn = (lambda a=d_arena, o=d_out: ctx.ipv4_validate_dev(a.data_ptr(), n, ifc, o.data_ptr(), stream))
-            kernel = "k_ipv4_validate"
-        else:
-            d_off = torch.from_numpy(off16).cuda()
-            d_len = torch.from_numpy(lens).cuda()
-            ctx.synth_dev(kind, SEED, f_idx, n, ifc, d_off.data_ptr(), d_len.data_ptr(), d_arena.data_ptr(), nbytes, stream)
-            alg_bytes = int(lens.astype(np.int64).sum()) + 8 * n  # record bytes + 4 (length) + 4 (result)
-            off_ptr = None if stride16 else d_off.data_ptr()
-            fn = (lambda a=d_arena, o=d_out, l=d_len, op=off_ptr, nb=nbytes:
-                  ctx.verify_dev(a.data_ptr(), nb, op, stride16, l.data_ptr(), n, ifc, o.data_ptr(), stream))
-            kernel = "k_verify<MODE_L3>"
-            keep.append((d_off, d_len))
-        steps_fns.append(fn)
-        keep.append((d_arena, d_out))
-        if r == 0:
-            d_arena0, d_out0, nbytes0, alg_bytes0 = d_arena, d_out, nbytes, alg_bytes
-    d_arena, d_out, nbytes, alg_bytes = d_arena0, d_out0, nbytes0, alg_bytes0
-    counter = [0]
-
-    def step():
-        steps_fns[counter[0] % rotate]()
-        counter[0] += 1
+    batches = [Batch(ctx, stream, kind, ifc, r * n_global, n_global, shard_world, shard_rank, stride16) for r in range(rotate)]
+    b0 = batches[0]
+    kernel = "k_ipv4_validate" if kind == unet_amd.SYNTH_IPV4_HDR20 else "k_verify<MODE_L3>"
     torch.cuda.synchronize()
 
     # ---- timed region
+    k = 0
     for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
+        batches[k % rotate].run()
+        k += 1
+    sync_all()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(args.steps):
-        step()
+        batches[k % rotate].run()
+        k += 1
     ev1.record()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
+    sync_all()
     wall = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
     wall = shard.max_over_ranks(wall, "cuda", dist)
 
     # ---- epilogue: per-verdict counters, summed across GPUs (the only cross-GPU traffic)
-    d_cnt = torch.zeros(32, dtype=torch.int64, device="cuda")
-    ctx.count_verdicts_dev(d_out.data_ptr(), n, d_cnt.data_ptr(), stream)
+    d_cnt = b0.counts()
     torch.cuda.synchronize()
     local_cnt = d_cnt.cpu().numpy().copy()
     cnt = shard.allreduce_counts(d_cnt, dist).cpu().numpy()
+    sizes_t = torch.tensor([sum(b.n for b in batches), sum(b.alg_bytes for b in batches)], dtype=torch.int64, device="cuda")
+    all_sizes, all_bytes = [int(sizes_t[0].item())], [int(sizes_t[1].item())]
+    if dist:
+        gathered = [torch.zeros_like(sizes_t) for _ in range(world)]
+        dist.all_gather(gathered, sizes_t)
+        all_sizes = [int(g[0].item()) for g in gathered]
+        all_bytes = [int(g[1].item()) for g in gathered]
+    frames_per_step_all = sum(all_sizes) / rotate  # records judged per step over all ranks
     parity = None
     if args.workload == "udp1500":
         # per-index fault rules of the trace: idx % 256 == 33 -> length mismatch; idx % 64 == 7 or
         # idx % 256 == 97 -> checksum failure (a zeroed field can verify only if the true value was 0)
-        idx = np.arange(first_idx, first_idx + n, dtype=np.int64)
+        idx = b0.trace_indices()
         n_len = int((idx % 256 == 33).sum())
         n_ck = int(((idx % 64 == 7) | (idx % 256 == 97)).sum())
         parity = bool(local_cnt[Verdict.DROP_UDP_LEN] == n_len and n_ck - 16 <= local_cnt[Verdict.DROP_UDP_CSUM] <= n_ck
-                      and local_cnt[Verdict.ACCEPT_UDP] == n - n_len - local_cnt[Verdict.DROP_UDP_CSUM])
+                      and local_cnt[Verdict.ACCEPT_UDP] == b0.n - n_len - local_cnt[Verdict.DROP_UDP_CSUM])
 
     # ---- attainable-bandwidth yardstick: read-only streaming kernel over the same buffer
     d_sink = torch.zeros(4096, dtype=torch.int32, device="cuda")
     for _ in range(2):
-        ctx.stream_read_dev(d_arena.data_ptr(), nbytes, d_sink.data_ptr(), stream)
+        ctx.stream_read_dev(b0.arena.data_ptr(), b0.nbytes, d_sink.data_ptr(), stream)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(10):
-        ctx.stream_read_dev(d_arena.data_ptr(), nbytes, d_sink.data_ptr(), stream)
+        ctx.stream_read_dev(b0.arena.data_ptr(), b0.nbytes, d_sink.data_ptr(), stream)
     e1.record()
     torch.cuda.synchronize()
-    stream_gbps = nbytes * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    stream_gbps = b0.nbytes * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
     if rank == 0:
+        alg_bytes = sum(b.alg_bytes for b in batches) / rotate
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC passes of this same command (tools/pmc_traffic.py), if the
         # committed measurement matches this workload and batch size
         traffic = None
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(args.workload)
-            if rec and rec["frames"] == n:
+            if rec and rec["frames"] == b0.n and shard_world == 1:
                 traffic = rec["traffic_bytes"]
         except (OSError, ValueError, KeyError):
             pass
+        if shard_world == 1:
+            sharding = "single GPU, contiguous trace indices"
+        elif kind == unet_amd.SYNTH_IPV4_HDR20:
+            sharding = "index ranges (bare headers)"
+        else:
+            sharding = f"5-tuple flow hash % {shard_world} over a global batch of {n_global} records"
         line = {
             "metric": "Gpkt/s and achieved HBM GB/s, batched IPv4+TCP/UDP checksum+parse, 1500B",
-            "value": n * world * args.steps / wall / 1e9,
+            "value": frames_per_step_all * args.steps / wall / 1e9,
             "unit": "Gpkt/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -208,17 +334,17 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": {"udp1500": "4,194,304 x 1500-byte IPv4/UDP packets per GPU (BASELINE configs[2])",
-                                    "imix": "8,388,608 mixed 64-9000-byte TCP/UDP/ICMP packets per GPU (BASELINE configs[3])",
-                                    "hdr20": "16,777,216 bare 20-byte IPv4 headers per GPU (BASELINE configs[1])"}[args.workload],
-                       "frames_per_gpu": n, "arena_bytes_per_gpu": nbytes, "ext_tcp": ext_tcp, "batches_rotated": rotate,
-                       "sharding": "disjoint index ranges per rank, no data-path collective; counters all-reduced (RCCL) after the timed region",
-                       "inputs": "generated in HBM by unet_synth_dev before the timed region"},
+            "config": {"workload": DESCRIPTION[args.workload], "frames_per_gpu": n_per_gpu, "rank0_frames": b0.n,
+                       "arena_bytes_rank0": b0.nbytes, "ext_tcp": ext_tcp, "batches_rotated": rotate,
+                       "sharding": sharding, "shard_sizes": [s // rotate for s in all_sizes],
+                       "shard_skew_max_over_mean": max(all_sizes) / (sum(all_sizes) / len(all_sizes)),
+                       "collectives": "none on the data path; 32 u64 verdict counters all-reduced (RCCL) after the timed region",
+                       "inputs": "generated in HBM by unet_synth_indexed_dev before the timed region"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": kernel,
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "stream_read_GBps": stream_gbps, "frac_of_stream_read": achieved / stream_gbps},
-            "hbm_GBps_all_gpus": alg_bytes * world * args.steps / wall / 1e9,
+            "hbm_GBps_all_gpus": sum(all_bytes) / rotate * args.steps / wall / 1e9,
             "verdict_counts": {Verdict(i).name: int(c) for i, c in enumerate(cnt) if c},
             "parity_check": parity,
         }
