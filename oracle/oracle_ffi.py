@@ -59,6 +59,8 @@ def lib():
         L.oracle_generate.argtypes = [vp, C.c_size_t]
         L.oracle_recv_batch.restype = None
         L.oracle_recv_batch.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.POINTER(IfaceC), vp]
+        L.oracle_recv_batch_fast.restype = None
+        L.oracle_recv_batch_fast.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.POINTER(IfaceC), vp]
         L.oracle_csum_batch.restype = None
         L.oracle_csum_batch.argtypes = [vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp]
         L.oracle_ipv4_validate_batch.restype = None
@@ -110,15 +112,17 @@ def recv(rec: bytes, iface):
     return _res(lib().oracle_recv(rec, len(rec), C.byref(ic)))
 
 
-def recv_batch(arena: np.ndarray, off16, lens: np.ndarray, iface, stride16: int = 0) -> np.ndarray:
+def recv_batch(arena: np.ndarray, off16, lens: np.ndarray, iface, stride16: int = 0, fast: bool = False) -> np.ndarray:
+    """fast=True computes the same verdicts with the 64-bit-accumulator checksum."""
     arena = np.ascontiguousarray(arena, dtype=np.uint8)
     lens = np.ascontiguousarray(lens, dtype=np.uint32)
     if off16 is not None:
         off16 = np.ascontiguousarray(off16, dtype=np.uint32)
     out = np.zeros(len(lens), dtype=RESULT_DTYPE)
     ic = iface_c(iface)
-    lib().oracle_recv_batch(arena.ctypes.data, None if off16 is None else off16.ctypes.data, stride16, lens.ctypes.data,
-                            len(lens), C.byref(ic), out.ctypes.data)
+    fn = lib().oracle_recv_batch_fast if fast else lib().oracle_recv_batch
+    fn(arena.ctypes.data, None if off16 is None else off16.ctypes.data, stride16, lens.ctypes.data,
+       len(lens), C.byref(ic), out.ctypes.data)
     return out
 
 

@@ -74,6 +74,13 @@ uint16_t oracle_calculate_checksum_fast(const uint8_t* data, size_t len, uint16_
 
 /* ------------------------------------------------------------ helpers */
 
+/* Which checksum routine the verdict code calls: the faithful 2-byte loop (default) or the 64-bit
+ * accumulator.  Thread-local so that concurrent batch drivers can differ. */
+static __thread int g_use_fast = 0;
+static uint16_t csum_of(const uint8_t* data, size_t len, uint16_t sum) {
+    return g_use_fast ? oracle_calculate_checksum_fast(data, len, sum) : oracle_calculate_checksum(data, len, sum);
+}
+
 static uint16_t be16(const uint8_t* p) { return (uint16_t)(((uint16_t)p[0] << 8) | p[1]); }
 static uint32_t be32(const uint8_t* p) {
     return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
@@ -127,7 +134,7 @@ oracle_result oracle_ipv4_header_validate(const uint8_t* b, int ext_tcp) {
      * of a longer header are NOT part of it. */
     uint8_t copy[20];
     memcpy(copy, b, 20);
-    uint16_t ck = oracle_calculate_checksum(copy, 20, 0);
+    uint16_t ck = csum_of(copy, 20, 0);
     if (ck != 0) return mk(OV_DROP_L3_CSUM, proto, ck);
     return mk(OV_L3_HEADER_OK, proto, 0);
 }
@@ -137,7 +144,7 @@ oracle_result oracle_ipv4_header_validate(const uint8_t* b, int ext_tcp) {
 /* udp::recv up to the checksum decision, src/transport/udp.rs:219-254. */
 static oracle_result udp_recv(const uint8_t* seg, size_t len, uint32_t src, uint32_t dst) {
     if (len < 8) return mk(OV_DROP_UDP_SHORT, 17, 0);                             /* :225-228 */
-    uint16_t sum = oracle_calculate_checksum(seg, len, 0);                        /* :229 */
+    uint16_t sum = csum_of(seg, len, 0);                        /* :229 */
     uint16_t length = be16(seg + 4);                                              /* :57-66 */
     if (len != (size_t)length) return mk(OV_DROP_UDP_LEN, 17, 0);                 /* :232-238 */
     uint8_t pseudo[12];                                                           /* :26-36, :240-246 */
@@ -146,7 +153,7 @@ static oracle_result udp_recv(const uint8_t* seg, size_t len, uint32_t src, uint
     pseudo[8] = 0;
     pseudo[9] = 17;
     put_be16(pseudo + 10, length);
-    uint16_t fin = oracle_calculate_checksum(pseudo, 12, (uint16_t)~sum);         /* :247 */
+    uint16_t fin = csum_of(pseudo, 12, (uint16_t)~sum);         /* :247 */
     if (fin != 0) return mk(OV_DROP_UDP_CSUM, 17, fin);                           /* :248-254 */
     return mk(OV_ACCEPT_UDP, 17, 0);
 }
@@ -157,14 +164,14 @@ static oracle_result tcp_recv_ext(const uint8_t* seg, size_t len, uint32_t src, 
     if (len < 20) return mk(OV_DROP_TCP_SHORT, 6, 0);
     uint32_t doff = seg[12] >> 4;
     if (doff < 5 || doff * 4 > len) return mk(OV_DROP_TCP_DOFF, 6, 0);
-    uint16_t sum = oracle_calculate_checksum(seg, len, 0);
+    uint16_t sum = csum_of(seg, len, 0);
     uint8_t pseudo[12];
     put_be32(pseudo, src);
     put_be32(pseudo + 4, dst);
     pseudo[8] = 0;
     pseudo[9] = 6;
     put_be16(pseudo + 10, (uint16_t)len);
-    uint16_t fin = oracle_calculate_checksum(pseudo, 12, (uint16_t)~sum);
+    uint16_t fin = csum_of(pseudo, 12, (uint16_t)~sum);
     if (fin != 0) return mk(OV_DROP_TCP_CSUM, 6, fin);
     return mk(OV_ACCEPT_TCP, 6, 0);
 }
@@ -181,8 +188,8 @@ uint16_t oracle_icmp_send_checksum(uint8_t type, uint8_t code, uint32_t values, 
     hdr[3] = 0;
     put_be32(hdr + 4, values);
     /* ck(hdr || data, 0): chain through the seed.  An 8-byte prefix keeps word alignment. */
-    uint16_t part = oracle_calculate_checksum(hdr, 8, 0);
-    return oracle_calculate_checksum(data, data_len, (uint16_t)~part);
+    uint16_t part = csum_of(hdr, 8, 0);
+    return csum_of(data, data_len, (uint16_t)~part);
 }
 
 /* icmp::recv, src/transport/icmp.rs:97-122.  IcmpHeader::try_from (:48-63) reads data[0]
@@ -263,10 +270,10 @@ uint16_t oracle_udp_send_checksum(uint32_t src, uint32_t dst, uint16_t sport, ui
     put_be16(hdr + 2, dport);
     put_be16(hdr + 4, length);
     put_be16(hdr + 6, 0);
-    uint16_t s = oracle_calculate_checksum(pseudo, 12, 0);                        /* :200 */
+    uint16_t s = csum_of(pseudo, 12, 0);                        /* :200 */
     /* ck(hdr || payload, !s), chained through the seed across the 8-byte header */
-    uint16_t h = oracle_calculate_checksum(hdr, 8, (uint16_t)~s);
-    return oracle_calculate_checksum(payload, payload_len, (uint16_t)~h);         /* :202 */
+    uint16_t h = csum_of(hdr, 8, (uint16_t)~s);
+    return csum_of(payload, payload_len, (uint16_t)~h);         /* :202 */
 }
 
 /* create_ip_header, src/protocols/ipv4.rs:366-391. */
@@ -284,7 +291,7 @@ void oracle_create_ip_header(uint16_t id, uint8_t protocol, uint32_t src, uint32
     out[11] = 0;
     put_be32(out + 12, src);
     put_be32(out + 16, dst);
-    uint16_t ck = oracle_calculate_checksum(out, 20, 0);                          /* :387 */
+    uint16_t ck = csum_of(out, 20, 0);                          /* :387 */
     put_be16(out + 10, ck);                                                       /* :388-389 */
 }
 
@@ -311,18 +318,18 @@ uint8_t oracle_generate(uint8_t* pkt, size_t len) {
         put_be16(pseudo + 10, (uint16_t)seglen);
         seg[6] = 0;
         seg[7] = 0;
-        uint16_t s = oracle_calculate_checksum(pseudo, 12, 0);
-        uint16_t c = oracle_calculate_checksum(seg, seglen, (uint16_t)~s);
+        uint16_t s = csum_of(pseudo, 12, 0);
+        uint16_t c = csum_of(seg, seglen, (uint16_t)~s);
         put_be16(seg + 6, c);
     } else {
         seg[2] = 0;
         seg[3] = 0;
-        uint16_t c = oracle_calculate_checksum(seg, seglen, 0);
+        uint16_t c = csum_of(seg, seglen, 0);
         put_be16(seg + 2, c);
     }
     pkt[10] = 0;
     pkt[11] = 0;
-    uint16_t hc = oracle_calculate_checksum(pkt, 20, 0);
+    uint16_t hc = csum_of(pkt, 20, 0);
     put_be16(pkt + 10, hc);
     return 0;
 }
@@ -341,10 +348,17 @@ void oracle_recv_batch(const uint8_t* arena, const uint32_t* off16, uint32_t str
     }
 }
 
+void oracle_recv_batch_fast(const uint8_t* arena, const uint32_t* off16, uint32_t stride16,
+                            const uint32_t* len, uint32_t n, const oracle_iface* iface, oracle_result* out) {
+    g_use_fast = 1;
+    oracle_recv_batch(arena, off16, stride16, len, n, iface, out);
+    g_use_fast = 0;
+}
+
 void oracle_csum_batch(const uint8_t* arena, const uint32_t* off16, uint32_t stride16,
                        const uint32_t* len, const uint16_t* seeds, uint32_t n, uint16_t* out) {
     for (uint32_t i = 0; i < n; i++) {
-        out[i] = oracle_calculate_checksum(rec_ptr(arena, off16, stride16, i), len[i],
+        out[i] = csum_of(rec_ptr(arena, off16, stride16, i), len[i],
                                            seeds ? seeds[i] : (uint16_t)0);
     }
 }

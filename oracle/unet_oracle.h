@@ -103,6 +103,9 @@ uint8_t oracle_generate(uint8_t* pkt, size_t len);
  * Record i starts at 16*off16[i] (or i*16*stride16 when off16 is NULL). */
 void oracle_recv_batch(const uint8_t* arena, const uint32_t* off16, uint32_t stride16,
                        const uint32_t* len, uint32_t n, const oracle_iface* iface, oracle_result* out);
+/* same verdicts, computed with oracle_calculate_checksum_fast: the "best effort CPU" line */
+void oracle_recv_batch_fast(const uint8_t* arena, const uint32_t* off16, uint32_t stride16,
+                            const uint32_t* len, uint32_t n, const oracle_iface* iface, oracle_result* out);
 void oracle_csum_batch(const uint8_t* arena, const uint32_t* off16, uint32_t stride16,
                        const uint32_t* len, const uint16_t* seeds, uint32_t n, uint16_t* out);
 void oracle_ipv4_validate_batch(const uint8_t* hdrs, uint32_t n, int ext_tcp, oracle_result* out);

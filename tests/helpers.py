@@ -69,3 +69,28 @@ def random_lengths(rng, n, max_len=9000):
     pick = rng.random(n) < 0.4
     lens[k:] = np.where(pick[k:], small[k:], lens[k:])
     return lens.astype(np.uint32)
+
+
+def py_ck(data: bytes, seed: int = 0) -> int:
+    """src/utils.rs:1-17 in plain Python (third, independent implementation used by a few tests)."""
+    total = seed
+    for i in range(0, len(data), 2):
+        total += (data[i] << 8) | (data[i + 1] if i + 1 < len(data) else 0)
+    while total >> 16:
+        total = (total & 0xFFFF) + (total >> 16)
+    return (~total) & 0xFFFF
+
+
+def config1_echo_frame():
+    """BASELINE configs[0] stand-in: the 98-byte Ethernet frame of a 64-byte ICMP echo request sent by
+    the tap peer 192.0.2.1 to the stack's 192.0.2.2 (src/app.rs:42-54, setup_tap.sh)."""
+    import struct
+    tap_mac, peer_mac = b"\x02\x00\x5e\x10\x20\x30", b"\x02\xaa\xbb\xcc\xdd\xee"
+    data = bytes(range(56))
+    icmp = bytearray(struct.pack(">BBHI", 8, 0, 0, 0x12340001) + data)
+    struct.pack_into(">H", icmp, 2, py_ck(bytes(icmp)))
+    ip = bytearray(struct.pack(">BBHHHBBHII", 0x45, 0, 84, 0xBEEF, 0x4000, 64, 1, 0, 0xC0000201, 0xC0000202))
+    struct.pack_into(">H", ip, 10, py_ck(bytes(ip)))
+    frame = tap_mac + peer_mac + b"\x08\x00" + bytes(ip) + bytes(icmp)
+    assert len(frame) == 98
+    return frame, tap_mac, peer_mac

@@ -7,7 +7,7 @@ import pytest
 
 import unet_amd
 from unet_amd import Verdict
-from helpers import as_tuples, edge_data, iface_key, load, random_lengths, vector_iface, vector_record
+from helpers import as_tuples, config1_echo_frame, edge_data, iface_key, load, py_ck, random_lengths, vector_iface, vector_record
 from oracle import oracle_ffi as O
 
 pytestmark = pytest.mark.gpu
@@ -97,6 +97,33 @@ def test_udp_demo_vector(offload):
     assert status.tolist() == [0] and filled[26:28].tobytes() == b"\x80\x19"
     lo = unet_amd.Iface("127.0.0.1", "255.0.0.0")
     assert as_tuples(offload.verify(filled, off16, lens, lo)) == [(Verdict.ACCEPT_UDP, 17, 0)]
+
+
+def test_config1_single_icmp_echo_on_tap0(offload):
+    """configs[0] on the GPU path: verdict for the 98-byte echo frame, and the reply built with the
+    offload's own outputs (result.csum for ICMP, unet_generate for the IPv4 header) is byte-identical
+    to the reply the CPU restatement of the reference builds."""
+    frame, tap_mac, peer_mac = config1_echo_frame()
+    tap = unet_amd.Iface("192.0.2.2", "255.255.255.0", mac=tap_mac, mode=unet_amd.MODE_L2)
+    res = offload.verify_frames([frame], tap)
+    assert as_tuples(res) == [O.recv(frame, tap)] and res["verdict"][0] == Verdict.ACCEPT_ICMP_ECHO
+    msg = frame[34:]
+    code, values, data = msg[1], struct.unpack(">I", msg[4:8])[0], msg[8:]
+    want_icmp = bytearray(struct.pack(">BBHI", 0, code, 0, values) + data)
+    struct.pack_into(">H", want_icmp, 2, O.icmp_send_checksum(0, code, values, data))
+    want = O.create_ip_header(0, 1, 0xC0000202, 0xC0000201, len(want_icmp)) + bytes(want_icmp)
+    # (a) reply ICMP checksum straight from the receive result
+    assert int(res["csum"][0]) == struct.unpack(">H", want_icmp[2:4])[0]
+    # (b) the whole reply with both checksum fields left blank, filled by the transmit-side kernel
+    blank = bytearray(want)
+    blank[10:12] = b"\0\0"
+    blank[22:24] = b"\0\0"
+    arena, off16, lens = unet_amd.pack_arena([bytes(blank)])
+    filled, status = offload.generate(arena, off16, lens)
+    assert status.tolist() == [0] and filled[:len(want)].tobytes() == want
+    reply = peer_mac + tap_mac + b"\x08\x00" + want
+    peer = unet_amd.Iface("192.0.2.1", "255.255.255.0", mac=peer_mac, mode=unet_amd.MODE_L2)
+    assert as_tuples(offload.verify_frames([reply], peer)) == [(Verdict.ACCEPT_ICMP_ECHOREPLY, 1, 0)]
 
 
 # ------------------------------------------------------------------ golden vectors

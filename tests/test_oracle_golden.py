@@ -5,7 +5,7 @@ import struct
 import numpy as np
 import pytest
 
-from helpers import as_tuples, edge_data, load, vector_iface, vector_record
+from helpers import as_tuples, config1_echo_frame, edge_data, load, py_ck, vector_iface, vector_record
 from oracle import oracle_ffi as O
 
 KATS = load("reference_kats.json")
@@ -155,3 +155,27 @@ def test_generate_then_verify_roundtrip():
         rec = filled[int(o) * 16:int(o) * 16 + len(f)].tobytes()
         if f[9] == 1:
             assert O.calculate_checksum(rec[20:], 0) == 0
+
+
+def test_config1_single_icmp_echo_on_tap0():
+    """The reference answering one 64-byte ICMP echo on tap0, restated on the CPU: receive verdict, then
+    the exact bytes of the reply the stack emits (icmp::recv -> icmp::send -> ipv4::send -> tap::send:
+    src/transport/icmp.rs:110-120,75-93, src/protocols/ipv4.rs:337-339,366-391, src/driver/tap.rs:138-152)."""
+    import unet_amd
+    frame, tap_mac, peer_mac = config1_echo_frame()
+    tap = unet_amd.Iface("192.0.2.2", "255.255.255.0", mac=tap_mac, mode=unet_amd.MODE_L2)
+    verdict, proto, reply_ck = O.recv(frame, tap)
+    assert (verdict, proto) == (15, 1)
+    msg = frame[34:]
+    code, values, data = msg[1], struct.unpack(">I", msg[4:8])[0], msg[8:]
+    reply_icmp = bytearray(struct.pack(">BBHI", 0, code, 0, values) + data)
+    assert reply_ck == py_ck(bytes(reply_icmp)) == O.icmp_send_checksum(0, code, values, data)
+    struct.pack_into(">H", reply_icmp, 2, reply_ck)
+    reply_ip = O.create_ip_header(0, 1, 0xC0000202, 0xC0000201, len(reply_icmp))  # first id of Ipv4IdGenerator is 0
+    assert reply_ip[:2] == b"\x45\x00" and struct.unpack(">H", reply_ip[2:4])[0] == 84 and reply_ip[8] == 64
+    assert py_ck(reply_ip) == 0
+    reply = peer_mac + tap_mac + b"\x08\x00" + reply_ip + bytes(reply_icmp)  # 98 bytes: no pad-to-60 needed
+    assert len(reply) == 98
+    peer = unet_amd.Iface("192.0.2.1", "255.255.255.0", mac=peer_mac, mode=unet_amd.MODE_L2)
+    assert O.recv(reply, peer) == (16, 1, 0)
+    assert py_ck(reply[34:]) == 0   # the peer's kernel does verify the ICMP checksum
