@@ -140,7 +140,7 @@ def load_library(path: Optional[str] = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("UNET_OFFLOAD_LIB") or LIB_PATH
     # PyTorch-ROCm wheels bundle their own libamdhip64.so.7.  A process must hold ONE HIP runtime: if
     # torch is going to be used beside this library (device buffers, torch.distributed), its runtime has
     # to be the one already mapped when ours is dlopen'ed, so that the loader resolves our DT_NEEDED to it.

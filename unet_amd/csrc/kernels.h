@@ -21,10 +21,21 @@ struct Batch {
     u32 n;
 };
 
-// Record bytes are read exactly once and never reused: non-temporal 16-byte loads keep them from
-// displacing anything in L2 / Infinity Cache (measured on MI355X: 7.0 TB/s streaming read with
-// them against 6.2 TB/s with default-policy loads).
+// Cache policy of the record loads.  Record bytes are read once, so the wave-wide row loads of a
+// streamed record are non-temporal (pure streaming read: 7.0 TB/s non-temporal vs 6.2 TB/s default on
+// MI355X).  But records are only 16-byte aligned: in the lane-parallel path neighbouring lanes pull
+// pieces of the same 128-byte lines with separate instructions, and a non-temporal load does not
+// leave the line behind for the next touch -- those loads use the default policy (measured on the
+// 64..9000-byte mix: 6.1 TB/s against 5.7 TB/s all non-temporal; 1500-byte packets are unaffected).
+// Knob for experiments (bit set = non-temporal): 1 rows 0/1 of a streamed record, 2 lane-parallel
+// records, 4 the loop past 2 KiB.  ld_stream() is always non-temporal (bandwidth yardstick).
+#ifndef UNET_NT_MASK
+#define UNET_NT_MASK 1
+#endif
 __device__ __forceinline__ u32x4 ld_stream(const u32x4* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ u32x4 ld_row(const u32x4* p) { return (UNET_NT_MASK & 1) ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ u32x4 ld_small(const u32x4* p) { return (UNET_NT_MASK & 2) ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ u32x4 ld_far(const u32x4* p) { return (UNET_NT_MASK & 4) ? __builtin_nontemporal_load(p) : *p; }
 
 // ------------------------------------------------------------------------------------------------
 // Tile machinery shared by k_verify, k_csum and k_generate.
@@ -97,8 +108,8 @@ __device__ __forceinline__ Rows2 issue_rows(const Batch& b, u32 my_len, u32 my_s
     x.nch = live ? (x.flen + 15u) >> 4 : 0u;
     x.p = reinterpret_cast<const u32x4*>(b.arena + (live ? (u64)slot * 16u : 0ull));
     const u32 last = x.nch != 0u ? x.nch - 1u : 0u;
-    x.r0 = ld_stream(x.p + min(lane, last));
-    x.r1 = ld_stream(x.p + min(lane + kWave, last));
+    x.r0 = ld_row(x.p + min(lane, last));
+    x.r1 = ld_row(x.p + min(lane + kWave, last));
     return x;
 }
 
@@ -134,10 +145,10 @@ __device__ __forceinline__ u32 stream_one(const Rows2& cur, u32 lane, u32x4* __r
     for (u32 c0 = 2u * kWave; c0 < nfull; c0 += 4u * kWave) {
         const u32 k0 = c0 + lane, k1 = k0 + kWave, k2 = k1 + kWave, k3 = k2 + kWave;
         u32x4 v0 = {0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
-        if (k0 < nfull) v0 = ld_stream(cur.p + k0);
-        if (k1 < nfull) v1 = ld_stream(cur.p + k1);
-        if (k2 < nfull) v2 = ld_stream(cur.p + k2);
-        if (k3 < nfull) v3 = ld_stream(cur.p + k3);
+        if (k0 < nfull) v0 = ld_far(cur.p + k0);
+        if (k1 < nfull) v1 = ld_far(cur.p + k1);
+        if (k2 < nfull) v2 = ld_far(cur.p + k2);
+        if (k3 < nfull) v3 = ld_far(cur.p + k3);
         acc = sum_chunk(v0, acc);
         acc = sum_chunk(v1, acc);
         acc = sum_chunk(v2, acc);
@@ -192,7 +203,7 @@ __device__ __forceinline__ u32 tile_sums(const Batch& b, const Tile& t, u32x4* _
     // fetches it now, long before it is needed
     const bool my_far = my_big && my_partial && (t.my_len >> 4) >= 2u * kWave;
     u32x4 far_cut = {0, 0, 0, 0};
-    if (my_far) far_cut = ld_stream(reinterpret_cast<const u32x4*>(b.arena + (u64)t.my_slot * 16u) + (t.my_len >> 4));
+    if (my_far) far_cut = ld_far(reinterpret_cast<const u32x4*>(b.arena + (u64)t.my_slot * 16u) + (t.my_len >> 4));
 
     // ---- lane-parallel records: each lane pulls its own 1..8 chunks.  Straight-line code per group
     // of four: unconditional loads (indices past the end re-read the last chunk and are zeroed by
@@ -203,7 +214,7 @@ __device__ __forceinline__ u32 tile_sums(const Batch& b, const Tile& t, u32x4* _
         const u32 k0 = my_partial ? tail.m0 : 0xffffffffu, k1 = my_partial ? tail.m1 : 0xffffffffu;
         const u32 k2 = my_partial ? tail.m2 : 0xffffffffu, k3 = my_partial ? tail.m3 : 0xffffffffu;
         u32 acc = 0;
-#define UNET_SMALL_LOAD(i) const u32x4 s##i = ld_stream(p + min((u32)(i), last))
+#define UNET_SMALL_LOAD(i) const u32x4 s##i = ld_small(p + min((u32)(i), last))
 #define UNET_SMALL_USE(i)                                                           \
         {                                                                           \
             if (PARK_HDR && (i) < kHdrChunks) mine[i] = s##i;                       \
