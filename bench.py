@@ -42,12 +42,17 @@ WORKLOADS = {
     "imix": (unet_amd.SYNTH_IMIX, 1 << 23, 0),
     "hdr20": (unet_amd.SYNTH_IPV4_HDR20, 1 << 24, 0),
     "trace": (unet_amd.SYNTH_FLOWS, 1 << 24, 0),
+    # the other entry points over the udp1500 batch
+    "csum": (unet_amd.SYNTH_UDP1500, 1 << 22, 94),
+    "generate": (unet_amd.SYNTH_UDP1500, 1 << 22, 94),
 }
 DESCRIPTION = {
     "udp1500": "4,194,304 x 1500-byte IPv4/UDP packets per GPU (BASELINE configs[2])",
     "imix": "8,388,608 mixed 64-9000-byte TCP/UDP/ICMP packets per GPU (BASELINE configs[3])",
     "hdr20": "16,777,216 bare 20-byte IPv4 headers per GPU (BASELINE configs[1])",
     "trace": "flow-table trace (2^20 flows, IMIX sizes) generated in HBM in chunks of 16,777,216 records per GPU (BASELINE configs[4])",
+    "csum": "calculate_checksum over 4,194,304 x 1500-byte records per GPU (unet_csum_batch_dev)",
+    "generate": "transmit-side checksum fill of 4,194,304 x 1500-byte IPv4/UDP packets per GPU, in place (unet_generate_dev)",
 }
 
 
@@ -98,8 +103,8 @@ def cpu_baseline(kind, ifc, budget_s):
 class Batch:
     """One resident batch of a rank: arena + tables + result buffer in HBM."""
 
-    def __init__(self, ctx, stream, kind, ifc, first_idx, n_global, world, rank, stride16):
-        self.kind, self.ifc, self.ctx, self.stream = kind, ifc, ctx, stream
+    def __init__(self, ctx, stream, kind, ifc, first_idx, n_global, world, rank, stride16, op="verify"):
+        self.kind, self.ifc, self.ctx, self.stream, self.op = kind, ifc, ctx, stream, op
         self.rel = None
         if kind == unet_amd.SYNTH_IPV4_HDR20:
             # bare headers carry no usable flow state: ranks take index ranges
@@ -133,9 +138,21 @@ class Batch:
             self.alg_bytes = int(self.len.to(torch.int64).sum().item()) + 8 * self.n  # bytes + 4 (length) + 4 (result)
             self.stride16 = stride16
         self.out = torch.zeros(self.n, dtype=torch.int32, device="cuda")
+        if op == "csum":
+            self.alg_bytes -= 2 * self.n      # 2-byte results
+        elif op == "generate":
+            self.alg_bytes += self.n          # 4 bytes of checksum fields + 1 status byte instead of a 4-byte result
 
     def run(self):
-        if self.kind == unet_amd.SYNTH_IPV4_HDR20:
+        if self.op == "csum":
+            off_ptr = None if self.stride16 else self.off.data_ptr()
+            self.ctx.csum_batch_dev(self.arena.data_ptr(), self.nbytes, off_ptr, self.stride16, self.len.data_ptr(), None,
+                                    self.n, self.out.data_ptr(), self.stream)
+        elif self.op == "generate":
+            off_ptr = None if self.stride16 else self.off.data_ptr()
+            self.ctx.generate_dev(self.arena.data_ptr(), self.nbytes, off_ptr, self.stride16, self.len.data_ptr(), self.n,
+                                  self.out.data_ptr(), self.stream)
+        elif self.kind == unet_amd.SYNTH_IPV4_HDR20:
             self.ctx.ipv4_validate_dev(self.arena.data_ptr(), self.n, self.ifc, self.out.data_ptr(), self.stream)
         else:
             off_ptr = None if self.stride16 else self.off.data_ptr()
@@ -273,9 +290,10 @@ def main():
     # rotated over several distinct batches (consecutive index ranges of the same trace) so that no
     # launch finds its input in cache.
     rotate = args.rotate if args.rotate else (6 if kind == unet_amd.SYNTH_IPV4_HDR20 else 1)
-    batches = [Batch(ctx, stream, kind, ifc, r * n_global, n_global, shard_world, shard_rank, stride16) for r in range(rotate)]
+    op = args.workload if args.workload in ("csum", "generate") else "verify"
+    batches = [Batch(ctx, stream, kind, ifc, r * n_global, n_global, shard_world, shard_rank, stride16, op) for r in range(rotate)]
     b0 = batches[0]
-    kernel = "k_ipv4_validate" if kind == unet_amd.SYNTH_IPV4_HDR20 else "k_verify<MODE_L3>"
+    kernel = {"csum": "k_csum", "generate": "k_generate"}.get(op, "k_ipv4_validate" if kind == unet_amd.SYNTH_IPV4_HDR20 else "k_verify<MODE_L3>")
     torch.cuda.synchronize()
 
     # ---- timed region
@@ -297,6 +315,8 @@ def main():
     wall = shard.max_over_ranks(wall, "cuda", dist)
 
     # ---- epilogue: per-verdict counters, summed across GPUs (the only cross-GPU traffic)
+    if op == "csum":
+        b0.out.zero_()  # 16-bit checksums are not verdicts: nothing to count
     d_cnt = b0.counts()
     torch.cuda.synchronize()
     local_cnt = d_cnt.cpu().numpy().copy()
@@ -310,6 +330,15 @@ def main():
         all_bytes = [int(g[1].item()) for g in gathered]
     frames_per_step_all = sum(all_sizes) / rotate  # records judged per step over all ranks
     parity = None
+    if op == "generate":
+        # the fill is idempotent: the packets must still verify exactly as the trace rules say
+        b0.op = "verify"
+        b0.run()
+        d_cnt = b0.counts()
+        torch.cuda.synchronize()
+        local_cnt = d_cnt.cpu().numpy().copy()
+        cnt = shard.allreduce_counts(d_cnt, dist).cpu().numpy()
+        parity = bool(local_cnt[Verdict.ACCEPT_UDP] + local_cnt[Verdict.DROP_UDP_LEN] == b0.n)
     if args.workload == "udp1500":
         # per-index fault rules of the trace: idx % 256 == 33 -> length mismatch; idx % 64 == 7 or
         # idx % 256 == 97 -> checksum failure (a zeroed field can verify only if the true value was 0)

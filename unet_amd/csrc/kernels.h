@@ -189,14 +189,29 @@ __device__ __forceinline__ u32 tile_sums(const Batch& b, const Tile& t, u32x4* _
     const bool my_partial = (t.my_len & 15u) != 0u;
     u32 my_total = 0;
 
-    // ---- streamed records: first pair of loads goes out before anything else
+    // ---- streamed records: the first loads go out before anything else
     u64 todo = __ballot(my_big);
+#ifndef UNET_DEPTH
+#define UNET_DEPTH 3  // register buffers in rotation: two records' loads in flight while a third is summed
+#endif
     Rows2 A, B;
-    A.live = false;
-    if (todo != 0ull) {
-        const u32 jA = (u32)__builtin_ctzll(todo);
-        todo &= todo - 1ull;
-        A = issue_rows(b, t.my_len, t.my_slot, t.lane, jA, true);
+#if UNET_DEPTH == 3
+    Rows2 C;
+#endif
+    // next record to stream, or a dummy (same number of load instructions) once the list is empty
+#define UNET_NEXT(R)                                                                 \
+    {                                                                                \
+        const bool has = todo != 0ull;                                               \
+        const u32 j = has ? (u32)__builtin_ctzll(todo) : 0u;                         \
+        todo &= todo - 1ull;                                                         \
+        R = issue_rows(b, t.my_len, t.my_slot, t.lane, j, has);                      \
+    }
+    const bool any_big = todo != 0ull;
+    if (any_big) {
+        UNET_NEXT(A)
+#if UNET_DEPTH == 3
+        UNET_NEXT(B)
+#endif
     }
 
     // ---- the cut last chunk of a record longer than 2 KiB is not held in rows 0/1: its own lane
@@ -237,27 +252,38 @@ __device__ __forceinline__ u32 tile_sums(const Batch& b, const Tile& t, u32x4* _
         my_total = acc;
     }
 
-    // ---- stream the long records, two register buffers used alternately (no register copies, so
-    // nothing forces an early wait)
-    if (A.live) {
+    // ---- stream the long records; the register buffers are used in rotation (no register copies, so
+    // nothing forces an early wait) and the loads of the next record(s) are in flight while one is summed
+#define UNET_CONSUME(R)                                                              \
+    {                                                                                \
+        const u32 s_ = stream_one<PARK_HDR>(R, t.lane, park);                        \
+        if (t.lane == R.j) my_total = s_;                                            \
+    }
+    if (any_big) {
 #pragma nounroll
         while (true) {
-            const bool hasB = todo != 0ull;
-            const u32 jB = hasB ? (u32)__builtin_ctzll(todo) : A.j;
-            todo &= todo - 1ull;
-            B = issue_rows(b, t.my_len, t.my_slot, t.lane, jB, hasB);
-            const u32 sA = stream_one<PARK_HDR>(A, t.lane, park);
-            if (t.lane == A.j) my_total = sA;
-            if (!hasB) break;
-            const bool hasA = todo != 0ull;
-            const u32 jA = hasA ? (u32)__builtin_ctzll(todo) : B.j;
-            todo &= todo - 1ull;
-            A = issue_rows(b, t.my_len, t.my_slot, t.lane, jA, hasA);
-            const u32 sB = stream_one<PARK_HDR>(B, t.lane, park);
-            if (t.lane == B.j) my_total = sB;
-            if (!hasA) break;
+#if UNET_DEPTH == 3
+            UNET_NEXT(C)
+            UNET_CONSUME(A)
+            if (!B.live) break;
+            UNET_NEXT(A)
+            UNET_CONSUME(B)
+            if (!C.live) break;
+            UNET_NEXT(B)
+            UNET_CONSUME(C)
+            if (!A.live) break;
+#else
+            UNET_NEXT(B)
+            UNET_CONSUME(A)
+            if (!B.live) break;
+            UNET_NEXT(A)
+            UNET_CONSUME(B)
+            if (!A.live) break;
+#endif
         }
     }
+#undef UNET_NEXT
+#undef UNET_CONSUME
 
     // ---- LDS written by other lanes of this wave is read back below and by the caller
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -369,23 +395,25 @@ __global__ __launch_bounds__(kBlock, TILE == 64 ? 5 : 6) void k_generate(Batch b
         else if (seglen < 8u) st = proto == 17u ? V_DROP_UDP_SHORT : V_DROP_ICMP_TRUNCATED;
         else {
             st = 0;
-            uint8_t* rec = arena_rw + (u64)t.my_slot * 16u;
             // IPv4 header field zeroed, then summed (src/protocols/ipv4.rs:374-389)
             const u32 hdr = halves(w0) + halves(w1) + (w2 & 0xffffu) + halves(w3) + halves(w4);
             const u32 prefix = hdr + (w2 >> 16);
-            u32 l4ck, l4off;
+            u32 w5 = w[5], w6 = w[6];
             if (proto == 17u) {
                 // s = ck(pseudo, 0); c = ck(hdr(cksum 0) || payload, !s)  (src/transport/udp.rs:200-203)
                 const u32 pseudo = halves(w3) + halves(w4) + 0x1100u + bswap16(seglen);
-                l4ck = finish(total - prefix - (w[6] >> 16) + pseudo);
-                l4off = 26u;
+                const u32 l4ck = finish(total - prefix - (w6 >> 16) + pseudo);
+                w6 = (w6 & 0xffffu) | (bswap16(l4ck) << 16);  // segment bytes 6..7 = packet bytes 26..27
             } else {
                 // ck(hdr(cksum 0) || data, 0)  (src/transport/icmp.rs:81-85)
-                l4ck = finish(total - prefix - (w[5] >> 16));
-                l4off = 22u;
+                const u32 l4ck = finish(total - prefix - (w5 >> 16));
+                w5 = (w5 & 0xffffu) | (bswap16(l4ck) << 16);  // message bytes 2..3 = packet bytes 22..23
             }
-            *reinterpret_cast<uint16_t*>(rec + 10) = (uint16_t)bswap16(finish(hdr));
-            *reinterpret_cast<uint16_t*>(rec + l4off) = (uint16_t)bswap16(l4ck);
+            // Both fields live in the packet's first 32 bytes: store those two chunks whole (full
+            // 32-byte sectors, no read-modify-write in the memory system) instead of two 2-byte pokes.
+            u32x4* rec = reinterpret_cast<u32x4*>(arena_rw + (u64)t.my_slot * 16u);
+            rec[0] = u32x4{w0, w1, (w2 & 0xffffu) | (bswap16(finish(hdr)) << 16), w3};
+            rec[1] = u32x4{w4, w5, w6, w[7]};
         }
     }
     if (status && t.lane < t.cnt) status[t.first + t.lane] = (uint8_t)st;
