@@ -1,0 +1,168 @@
+// Exercises unet_amd/host/unet_host.hpp.  `--cpu`: host logic only (arena packer, PCB table).
+// `--gpu`: the batched drain loop against the CPU oracle, packet by packet.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../oracle/unet_oracle.h"
+#include "../../unet_amd/host/unet_host.hpp"
+
+using namespace unet;
+
+static int g_fail = 0;
+#define CHECK(cond)                                                        \
+    do {                                                                   \
+        if (!(cond)) {                                                     \
+            std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);    \
+            g_fail++;                                                      \
+        }                                                                  \
+    } while (0)
+
+static std::vector<uint8_t> ip_packet(uint8_t proto, uint32_t src, uint32_t dst, const std::vector<uint8_t>& l4, uint16_t id = 7) {
+    std::vector<uint8_t> p(20 + l4.size());
+    oracle_create_ip_header(id, proto, src, dst, l4.size(), p.data());
+    std::memcpy(p.data() + 20, l4.data(), l4.size());
+    return p;
+}
+static std::vector<uint8_t> udp_segment(uint32_t src, uint32_t dst, uint16_t sport, uint16_t dport, const std::vector<uint8_t>& payload) {
+    std::vector<uint8_t> s(8 + payload.size());
+    put16(&s[0], sport);
+    put16(&s[2], dport);
+    put16(&s[4], uint16_t(s.size()));
+    std::memcpy(s.data() + 8, payload.data(), payload.size());
+    put16(&s[6], oracle_udp_send_checksum(src, dst, sport, dport, payload.data(), payload.size()));
+    return s;
+}
+static std::vector<uint8_t> icmp_message(uint8_t type, uint8_t code, uint32_t values, const std::vector<uint8_t>& data) {
+    std::vector<uint8_t> m(8 + data.size());
+    m[0] = type;
+    m[1] = code;
+    put32(&m[4], values);
+    std::memcpy(m.data() + 8, data.data(), data.size());
+    put16(&m[2], oracle_icmp_send_checksum(type, code, values, data.data(), data.size()));
+    return m;
+}
+
+static void cpu_tests() {
+    FrameArena a;
+    const uint8_t x[40] = {1, 2, 3};
+    CHECK(a.push(x, 0) == 0);
+    CHECK(a.push(x, 1) == 1);
+    CHECK(a.push(x, 16) == 2);
+    CHECK(a.push(x, 17) == 3);
+    CHECK(a.off16()[0] == 0 && a.off16()[1] == 0 && a.off16()[2] == 1 && a.off16()[3] == 2);
+    CHECK(a.bytes() == 64 && (reinterpret_cast<uintptr_t>(a.data()) & 15) == 0);
+    CHECK(a.record(3)[0] == 1 && a.record(3)[16] == 0 && a.record_len(3) == 17);
+    // udp::bind / select_pcb semantics, src/transport/udp.rs:84-165
+    UdpContext u;
+    const Ipv4Address any{0}, me{0xC0000202}, other{0xC0000203};
+    CHECK(u.bind(Endpoint{any, 8000}).value_or(99) == 0);
+    CHECK(!u.bind(Endpoint{me, 8000}).has_value());      // wildcard already holds the port
+    CHECK(u.bind(Endpoint{me, 8001}).value_or(99) == 1);
+    CHECK(!u.bind(Endpoint{any, 8001}).has_value());     // binding ANY collides with any address on that port
+    CHECK(u.bind(Endpoint{other, 8002}).value_or(99) == 2);
+    CHECK(u.select_pcb(me, 8000) == u.slot(0));
+    CHECK(u.select_pcb(other, 8001) == nullptr);
+    CHECK(u.select_pcb(other, 8002) == u.slot(2));
+    for (int i = 3; i < 16; i++) CHECK(u.bind(Endpoint{any, uint16_t(9000 + i)}).has_value());
+    CHECK(!u.bind(Endpoint{any, 9999}).has_value());     // 16 slots
+    Ipv4Interface tap(Ipv4Address{0xC0000202}, Ipv4Address{0xFFFFFF00});
+    CHECK(tap.broadcast.v == 0xC00002FF);
+    Ipv4Interface lo(Ipv4Address{0x7F000001}, Ipv4Address{0xFF000000});
+    CHECK(lo.broadcast.v == 0x7F0000FF);
+    Ipv4IdGenerator g;
+    CHECK(g.next() == 0 && g.next() == 1);
+}
+
+static void gpu_tests() {
+    Offload gpu(0);
+    // the reference's own checksum test, through the C++ wrapper (src/utils.rs:43-50)
+    const uint8_t kat[18] = {0x1f, 0x40, 0x1f, 0x41, 0x0, 0x1c, 0x0, 0x0, 0x30, 0x31, 0x32, 0x33, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39};
+    const uint16_t s = gpu.calculate_checksum(kat, 18, 0);
+    CHECK(s == 0xbc58 && gpu.calculate_checksum(kat, 18, s) == 0);
+
+    auto tap = std::make_shared<Ipv4Interface>(Ipv4Address{0xC0000202}, Ipv4Address{0xFFFFFF00});
+    auto lo = std::make_shared<Ipv4Interface>(Ipv4Address{0x7F000001}, Ipv4Address{0xFF000000});
+    lo->mtu = 65535;
+    const uint32_t peer = 0xC0000201, me = tap->unicast.v;
+    std::vector<uint8_t> pay(300), big(3000);
+    for (size_t i = 0; i < pay.size(); i++) pay[i] = uint8_t(i * 7 + 3);
+    for (size_t i = 0; i < big.size(); i++) big[i] = uint8_t(i * 13 + 1);
+
+    NetProtocol proto;
+    auto push = [&](std::vector<uint8_t> p, std::shared_ptr<Ipv4Interface> i) { proto.queue.push_back(Ipv4QueueEntry{std::move(p), std::move(i)}); };
+    push(ip_packet(17, peer, me, udp_segment(peer, me, 5000, 8000, pay)), tap);                       // 0 accepted, bound port
+    push(ip_packet(17, peer, me, udp_segment(peer, me, 5000, 8123, pay)), tap);                       // 1 accepted, no socket
+    push(ip_packet(1, peer, me, icmp_message(8, 0, 0x00800001, std::vector<uint8_t>(56, 0x5a))), tap); // 2 echo
+    push(ip_packet(1, peer, me, icmp_message(0, 0, 0x00800002, pay)), tap);                            // 3 echo reply
+    {
+        auto p = ip_packet(17, peer, me, udp_segment(peer, me, 1, 8000, pay));
+        p[100] ^= 0x10;
+        push(p, tap);                                                                                   // 4 bad udp checksum
+    }
+    push(ip_packet(6, peer, me, std::vector<uint8_t>(40, 0)), tap);                                    // 5 tcp, strict mode
+    push(ip_packet(1, 0x7F000001, 0x7F000001, icmp_message(8, 3, 42, big)), lo);                       // 6 echo on loopback, 3 KB
+    push(ip_packet(1, peer, tap->broadcast.v, icmp_message(8, 0, 1, pay)), tap);                       // 7 echo to broadcast
+    push(ip_packet(17, peer, 0xC0000299, udp_segment(peer, 0xC0000299, 1, 8000, pay)), tap);           // 8 not for me
+    push(ip_packet(17, peer, me, udp_segment(peer, me, 77, 8000, {})), tap);                           // 9 empty datagram
+    const std::vector<Ipv4QueueEntry> copy(proto.queue.begin(), proto.queue.end());
+
+    UdpContext pcbs;
+    CHECK(pcbs.bind(Endpoint{Ipv4Address{0}, 8000}).has_value());
+    Ipv4IdGenerator ids;
+    const RecvReport rep = proto.recv_batch(gpu, pcbs, ids);
+    CHECK(proto.queue.empty() && rep.results.size() == copy.size());
+
+    // every verdict equals the oracle's for the same bytes and interface
+    for (size_t i = 0; i < copy.size(); i++) {
+        const unet_iface ci = copy[i].interface->c_iface();
+        oracle_iface oi{};
+        std::memcpy(&oi, &ci, sizeof oi);
+        const oracle_result o = oracle_ipv4_recv(copy[i].data.data(), copy[i].data.size(), &oi);
+        CHECK(o.verdict == rep.results[i].verdict && o.csum == rep.results[i].csum && o.proto == rep.results[i].proto);
+    }
+    const int want[10] = {20, 20, 15, 16, 19, 6, 15, 15, 12, 20};
+    for (int i = 0; i < 10; i++) CHECK(rep.results[i].verdict == want[i]);
+
+    // UDP: two datagrams reached the bound socket, in queue order, with the reference's endpoint quirk
+    CHECK(rep.udp_enqueued == 2);
+    UdpContext::Pcb* sock = pcbs.slot(0);
+    CHECK(sock && sock->queue.size() == 2);
+    if (sock && sock->queue.size() == 2) {
+        CHECK(sock->queue[0].data == pay && sock->queue[0].foreign.port == 5000 && sock->queue[0].foreign.address.v == me);
+        CHECK(sock->queue[1].data.empty() && sock->queue[1].foreign.port == 77);
+    }
+    // errors: no socket, bad checksum, protocol 6, broadcast echo cannot be answered
+    CHECK(rep.errors.size() == 4);
+    bool saw_socket = false, saw_ck = false, saw_proto = false, saw_src = false;
+    for (const std::string& e : rep.errors) {
+        saw_socket |= e.find("udp socket not found, dst: 192.0.2.2, port: 8123") == 0;
+        saw_ck |= e.find("invalid udp checksum: 0x") == 0;
+        saw_proto |= e == "unknown transport protocol number: 6";
+        saw_src |= e.find("unable to send packet with the source address, src: 192.0.2.255") == 0;
+    }
+    CHECK(saw_socket && saw_ck && saw_proto && saw_src);
+
+    // replies: byte-identical to what icmp::send + create_ip_header produce on the CPU
+    CHECK(rep.replies.size() == 2);
+    if (rep.replies.size() == 2) {
+        // the loopback interface's packets form the second launch, so its reply takes the second id
+        const std::vector<uint8_t> r0 = ip_packet(1, me, peer, icmp_message(0, 0, 0x00800001, std::vector<uint8_t>(56, 0x5a)), 0);
+        const std::vector<uint8_t> r1 = ip_packet(1, 0x7F000001, 0x7F000001, icmp_message(0, 3, 42, big), 1);
+        CHECK(rep.replies[0].bytes == r0 && rep.replies[0].dst.v == peer);
+        CHECK(rep.replies[1].bytes == r1 && rep.replies[1].dst.v == 0x7F000001);
+    }
+}
+
+int main(int argc, char** argv) {
+    const std::string mode = argc > 1 ? argv[1] : "--cpu";
+    cpu_tests();
+    if (mode == "--gpu") gpu_tests();
+    if (g_fail) {
+        std::printf("%d check(s) failed\n", g_fail);
+        return 1;
+    }
+    std::printf("host_test %s ok\n", mode.c_str());
+    return 0;
+}

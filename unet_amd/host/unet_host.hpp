@@ -1,0 +1,357 @@
+// Host side of the offload for a C++ caller: the batching caller that replaces the reference's
+// per-packet drain loop, and the host-side follow-ups that act on the verdicts.
+//
+// The reference (Rust) handles one packet per call:
+//     NetProtocol::recv      src/protocols.rs:83-97     pops queue entries, calls ipv4::recv on each
+//     ipv4::recv             src/protocols/ipv4.rs:394-422
+//     udp::recv              src/transport/udp.rs:219-279   (validation, then PCB lookup + enqueue)
+//     icmp::recv / send      src/transport/icmp.rs:66-122   (echo -> echo reply)
+// Here the queue is drained into one arena, ONE unet_verify call decides every packet on the GPU, and
+// this file performs what the reference does after its checks have passed: UDP PCB lookup / enqueue
+// (udp.rs:256-277) and echo-reply construction (icmp.rs:110-120, ipv4.rs:337-339,366-391).  The replies'
+// IPv4 and ICMP checksums are filled by ONE unet_generate call: no checksum is computed on the host.
+//
+// Header-only, C++17, needs only include/unet_offload.h and the shared library.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/unet_offload.h"
+
+namespace unet {
+
+// ---------------------------------------------------------------------------------------------
+struct Ipv4Address {  // src/protocols/ipv4.rs:22-28
+    uint32_t v = 0;
+    static constexpr uint32_t ANY = 0x00000000u, BROADCAST = 0xffffffffu;
+    bool operator==(const Ipv4Address& o) const { return v == o.v; }
+    bool operator!=(const Ipv4Address& o) const { return v != o.v; }
+    std::string to_string() const {
+        return std::to_string(v >> 24) + "." + std::to_string((v >> 16) & 255) + "." + std::to_string((v >> 8) & 255) + "." +
+               std::to_string(v & 255);
+    }
+};
+
+struct Ipv4Interface {  // src/protocols/ipv4.rs:209-229
+    Ipv4Address unicast, netmask, broadcast;
+    std::array<uint8_t, 6> mac{};  // the owning device's hw_addr (src/devices.rs:75-90); L2 mode only
+    size_t mtu = 1500;             // src/devices/ethernet.rs:13 payload size; loopback uses 65535
+    Ipv4Interface(Ipv4Address u, Ipv4Address m) : unicast(u), netmask(m) {
+        broadcast.v = (u.v & 0xffffff00u) | (~m.v & 0xffu);  // ipv4.rs:220
+    }
+    unet_iface c_iface(bool l2 = false, bool ext_tcp = false) const {
+        unet_iface i{};
+        i.unicast = unicast.v;
+        i.broadcast = broadcast.v;
+        std::memcpy(i.mac, mac.data(), 6);
+        i.mode = l2 ? UNET_MODE_L2 : UNET_MODE_L3;
+        i.ext_tcp = ext_tcp ? 1 : 0;
+        return i;
+    }
+};
+
+struct Endpoint {  // src/transport.rs:30-43
+    Ipv4Address address;
+    uint16_t port = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Arena packer: every record starts on a 16-byte boundary of a 16-byte-aligned buffer.
+class FrameArena {
+  public:
+    FrameArena() = default;
+    FrameArena(const FrameArena&) = delete;
+    FrameArena& operator=(const FrameArena&) = delete;
+    ~FrameArena() { std::free(buf_); }
+
+    void clear() {
+        used_ = 0;
+        off16_.clear();
+        len_.clear();
+    }
+    // Appends one record; returns its index.
+    size_t push(const uint8_t* data, size_t n) {
+        if (n > 65535) throw std::length_error("record longer than 65535 bytes");
+        const size_t padded = (n + 15) & ~size_t(15);
+        reserve(used_ + padded);
+        off16_.push_back(static_cast<uint32_t>(used_ / 16));
+        len_.push_back(static_cast<uint32_t>(n));
+        if (n) std::memcpy(buf_ + used_, data, n);
+        if (padded > n) std::memset(buf_ + used_ + n, 0, padded - n);
+        used_ += padded;
+        return len_.size() - 1;
+    }
+    size_t size() const { return len_.size(); }
+    uint8_t* data() { reserve(16); return buf_; }
+    uint64_t bytes() const { return used_ < 16 ? 16 : used_; }
+    const uint32_t* off16() const { return off16_.data(); }
+    const uint32_t* len() const { return len_.data(); }
+    uint8_t* record(size_t i) { return buf_ + size_t(off16_[i]) * 16; }
+    uint32_t record_len(size_t i) const { return len_[i]; }
+
+  private:
+    void reserve(size_t want) {
+        if (want <= cap_) return;
+        size_t cap = cap_ ? cap_ : 4096;
+        while (cap < want) cap *= 2;
+        void* p = nullptr;
+        if (posix_memalign(&p, 64, cap) != 0) throw std::bad_alloc();
+        if (used_) std::memcpy(p, buf_, used_);
+        std::free(buf_);
+        buf_ = static_cast<uint8_t*>(p);
+        cap_ = cap;
+    }
+    uint8_t* buf_ = nullptr;
+    size_t cap_ = 0, used_ = 0;
+    std::vector<uint32_t> off16_, len_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// RAII handle on one GPU.
+class Offload {
+  public:
+    explicit Offload(int device = 0) {
+        if (unet_open(device, &ctx_) != UNET_OK) throw std::runtime_error(std::string("unet_open: ") + unet_last_error());
+    }
+    Offload(const Offload&) = delete;
+    Offload& operator=(const Offload&) = delete;
+    ~Offload() { unet_close(ctx_); }
+    unet_ctx* get() const { return ctx_; }
+
+    // `calculate_checksum(data, sum)` of src/utils.rs:1-17, on the GPU.
+    uint16_t calculate_checksum(const uint8_t* data, size_t len, uint16_t sum) const {
+        uint16_t out = 0;
+        if (unet_csum(ctx_, data, len, sum, &out) != UNET_OK) throw std::runtime_error(std::string("unet_csum: ") + unet_last_error());
+        return out;
+    }
+    std::vector<unet_result> verify(FrameArena& a, const unet_iface& iface) const {
+        std::vector<unet_result> out(a.size());
+        if (a.size() == 0) return out;
+        if (unet_verify(ctx_, a.data(), a.bytes(), a.off16(), 0, a.len(), static_cast<uint32_t>(a.size()), &iface, out.data()) != UNET_OK)
+            throw std::runtime_error(std::string("unet_verify: ") + unet_last_error());
+        return out;
+    }
+    std::vector<uint8_t> generate(FrameArena& a) const {
+        std::vector<uint8_t> status(a.size());
+        if (a.size() == 0) return status;
+        if (unet_generate(ctx_, a.data(), a.bytes(), a.off16(), 0, a.len(), static_cast<uint32_t>(a.size()), status.data()) != UNET_OK)
+            throw std::runtime_error(std::string("unet_generate: ") + unet_last_error());
+        return status;
+    }
+
+  private:
+    unet_ctx* ctx_ = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------------
+// UDP protocol control blocks: src/transport/udp.rs:68-165.
+struct UdpPcbQueueEntry {
+    Endpoint foreign;
+    std::vector<uint8_t> data;
+};
+
+class UdpContext {
+  public:
+    static constexpr size_t UDP_PCB_LENGTH = 16;  // udp.rs:15
+    struct Pcb {
+        bool open = true;  // PcbState::Open
+        Endpoint local;
+        std::deque<UdpPcbQueueEntry> queue;
+        // udp.rs:84-90
+        bool can_be_bound(Ipv4Address address, uint16_t port) const {
+            return open && (local.address.v == Ipv4Address::ANY || address.v == Ipv4Address::ANY || local.address == address) &&
+                   local.port == port;
+        }
+    };
+    // udp.rs:110-136: first PCB, in slot order, that can be bound
+    Pcb* select_pcb(Ipv4Address address, uint16_t port) {
+        for (auto& p : pcbs_)
+            if (p && p->can_be_bound(address, port)) return &*p;
+        return nullptr;
+    }
+    // udp::bind, udp.rs:139-165: nullopt when the endpoint is taken or the table is full
+    std::optional<size_t> bind(const Endpoint& e) {
+        if (select_pcb(e.address, e.port)) return std::nullopt;
+        for (size_t i = 0; i < pcbs_.size(); i++)
+            if (!pcbs_[i]) {
+                pcbs_[i] = Pcb{true, e, {}};
+                return i;
+            }
+        return std::nullopt;
+    }
+    Pcb* slot(size_t i) { return pcbs_[i] ? &*pcbs_[i] : nullptr; }
+
+  private:
+    std::array<std::optional<Pcb>, UDP_PCB_LENGTH> pcbs_{};
+};
+
+struct Ipv4IdGenerator {  // src/protocols/ipv4.rs:282-297
+    uint16_t id = 0;
+    uint16_t next() { return id++; }
+};
+
+// ---------------------------------------------------------------------------------------------
+struct Ipv4QueueEntry {  // src/protocols.rs:52-57
+    std::vector<uint8_t> data;
+    std::shared_ptr<Ipv4Interface> interface;
+};
+
+// An L3 packet the stack wants to transmit (what ipv4::send hands to the device layer after routing).
+struct TxPacket {
+    Ipv4Address dst;
+    std::vector<uint8_t> bytes;
+};
+
+struct RecvReport {
+    std::vector<unet_result> results;  // one per drained entry, in queue order
+    std::vector<std::string> errors;   // the reference's anyhow messages for dropped packets
+    std::vector<TxPacket> replies;     // echo replies, checksums filled
+    size_t udp_enqueued = 0;
+};
+
+inline uint16_t be16(const uint8_t* p) { return static_cast<uint16_t>((p[0] << 8) | p[1]); }
+inline uint32_t be32(const uint8_t* p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3]; }
+inline void put16(uint8_t* p, uint16_t v) { p[0] = uint8_t(v >> 8); p[1] = uint8_t(v); }
+inline void put32(uint8_t* p, uint32_t v) { p[0] = uint8_t(v >> 24); p[1] = uint8_t(v >> 16); p[2] = uint8_t(v >> 8); p[3] = uint8_t(v); }
+
+// The IPv4 protocol queue with a batched drain.
+class NetProtocol {
+  public:
+    std::deque<Ipv4QueueEntry> queue;  // src/protocols.rs:59-63
+
+    // Batched `NetProtocol::recv` (protocols.rs:83-97): every queued packet is decided by one offload call
+    // per interface.  Unlike the reference, a bad packet does not abort the drain (protocols.rs:92-93 leaves
+    // the rest queued until the next IRQ); each packet gets its own verdict and, if dropped, its own error.
+    RecvReport recv_batch(const Offload& gpu, UdpContext& pcbs, Ipv4IdGenerator& ids, bool ext_tcp = false) {
+        RecvReport rep;
+        std::vector<Ipv4QueueEntry> entries(std::make_move_iterator(queue.begin()), std::make_move_iterator(queue.end()));
+        queue.clear();
+        rep.results.resize(entries.size());
+        std::vector<char> done(entries.size(), 0);
+        FrameArena tx;
+        std::vector<Ipv4Address> tx_dst;
+        for (size_t first = 0; first < entries.size(); first++) {
+            if (done[first]) continue;
+            // one arena + one launch per distinct interface, queue order kept inside it
+            const Ipv4Interface* ifp = entries[first].interface.get();
+            arena_.clear();
+            std::vector<size_t> idx;
+            for (size_t i = first; i < entries.size(); i++)
+                if (!done[i] && entries[i].interface.get() == ifp) {
+                    arena_.push(entries[i].data.data(), entries[i].data.size());
+                    idx.push_back(i);
+                    done[i] = 1;
+                }
+            const unet_iface ci = ifp->c_iface(false, ext_tcp);
+            const std::vector<unet_result> res = gpu.verify(arena_, ci);
+            for (size_t k = 0; k < idx.size(); k++) {
+                rep.results[idx[k]] = res[k];
+                follow_up(entries[idx[k]], res[k], *ifp, pcbs, ids, rep, tx, tx_dst);
+            }
+        }
+        if (tx.size()) {
+            const std::vector<uint8_t> st = gpu.generate(tx);  // IPv4 + ICMP checksums of every reply
+            for (size_t i = 0; i < tx.size(); i++) {
+                if (st[i] != 0) { rep.errors.push_back("reply not filled, status " + std::to_string(st[i])); continue; }
+                rep.replies.push_back(TxPacket{tx_dst[i], std::vector<uint8_t>(tx.record(i), tx.record(i) + tx.record_len(i))});
+            }
+        }
+        return rep;
+    }
+
+  private:
+    FrameArena arena_;
+
+    static void follow_up(const Ipv4QueueEntry& e, const unet_result& r, const Ipv4Interface& ifc, UdpContext& pcbs,
+                          Ipv4IdGenerator& ids, RecvReport& rep, FrameArena& tx, std::vector<Ipv4Address>& tx_dst) {
+        const uint8_t* d = e.data.data();
+        switch (r.verdict) {
+            case UNET_V_ACCEPT_UDP: {  // udp.rs:256-277
+                const size_t hl = size_t(d[0] & 0x0f) * 4;
+                const Ipv4Address dst{be32(d + 16)};
+                const uint16_t sport = be16(d + hl), dport = be16(d + hl + 2);
+                UdpContext::Pcb* pcb = pcbs.select_pcb(dst, dport);
+                if (!pcb) {
+                    rep.errors.push_back("udp socket not found, dst: " + dst.to_string() + ", port: " + std::to_string(dport));
+                    break;
+                }
+                // the reference stores the DESTINATION address as the foreign endpoint (udp.rs:271-274)
+                pcb->queue.push_back(UdpPcbQueueEntry{Endpoint{dst, sport}, std::vector<uint8_t>(d + hl + 8, d + e.data.size())});
+                rep.udp_enqueued++;
+                break;
+            }
+            case UNET_V_ACCEPT_ICMP_ECHO: {  // icmp.rs:110-120 -> icmp::send -> ipv4::send
+                const size_t hl = size_t(d[0] & 0x0f) * 4;
+                const Ipv4Address req_src{be32(d + 12)}, req_dst{be32(d + 16)};
+                const uint8_t* msg = d + hl;
+                const size_t mlen = e.data.size() - hl;
+                // ipv4::send refuses a source that is not the interface address (ipv4.rs:324-329) ...
+                if (req_dst.v != Ipv4Address::ANY && req_dst != ifc.unicast) {
+                    rep.errors.push_back("unable to send packet with the source address, src: " + req_dst.to_string() +
+                                         ", interface: " + ifc.unicast.to_string());
+                    break;
+                }
+                // ... and a packet that does not fit the device (strict `<`, ipv4.rs:330-335)
+                if (!(mlen < ifc.mtu)) {
+                    rep.errors.push_back("packet too long, len: " + std::to_string(mlen) + ", mtu: " + std::to_string(ifc.mtu));
+                    break;
+                }
+                std::vector<uint8_t> p(20 + mlen);
+                // create_ip_header, ipv4.rs:366-391 (checksum field left 0: filled on the GPU)
+                p[0] = 0x45;
+                p[1] = 0;
+                put16(&p[2], uint16_t(20 + mlen));
+                put16(&p[4], ids.next());
+                put16(&p[6], 0);
+                p[8] = 64;
+                p[9] = 1;
+                put32(&p[12], ifc.unicast.v);
+                put32(&p[16], req_src.v);
+                // IcmpHeader{EchoReply, code, checksum 0, values} + data[8..], icmp.rs:75-82
+                p[20] = 0;
+                p[21] = msg[1];
+                std::memcpy(&p[24], msg + 4, mlen - 4);
+                tx.push(p.data(), p.size());
+                tx_dst.push_back(req_src);
+                break;
+            }
+            case UNET_V_ACCEPT_ICMP_ECHOREPLY:
+            case UNET_V_IGNORE_L3_NOT_FOR_ME:
+            case UNET_V_ACCEPT_TCP:
+                break;  // Ok(()) in the reference / nothing more on the host
+            default:
+                rep.errors.push_back(describe(r));
+        }
+    }
+
+    // The reference's error text for a dropped packet (anyhow messages at the cited lines).
+    static std::string describe(const unet_result& r) {
+        char hex[8];
+        std::snprintf(hex, sizeof hex, "%04x", r.csum);
+        switch (r.verdict) {
+            case UNET_V_DROP_L3_PROTO: return "unknown transport protocol number: " + std::to_string(r.proto);  // transport.rs:22-25
+            case UNET_V_DROP_L3_VERSION: return "invalid version";                                             // ipv4.rs:129-133
+            case UNET_V_DROP_L3_IHL_SHORT: return "ipv4 header too short";                                     // ipv4.rs:134-138
+            case UNET_V_DROP_L3_IHL_LONG: return "ipv4 header too long";                                       // ipv4.rs:139-143
+            case UNET_V_DROP_L3_FRAGMENT: return "fragmentation is not supported";                             // ipv4.rs:145-147
+            case UNET_V_DROP_L3_CSUM: return std::string("invalid checksum: ") + hex;                          // ipv4.rs:155
+            case UNET_V_DROP_ICMP_TYPE: return "unknown icmp type";                                            // icmp.rs:20
+            case UNET_V_DROP_UDP_SHORT: return "udp packet too short";                                         // udp.rs:227
+            case UNET_V_DROP_UDP_LEN: return "invalid udp packet length";                                      // udp.rs:233-237
+            case UNET_V_DROP_UDP_CSUM: return std::string("invalid udp checksum: 0x") + hex;                   // udp.rs:249-253
+            case UNET_V_DROP_L3_TRUNCATED:
+            case UNET_V_DROP_ICMP_TRUNCATED: return "truncated packet (the reference indexes out of bounds here)";
+            default: return "dropped, verdict " + std::to_string(r.verdict);
+        }
+    }
+};
+
+}  // namespace unet
