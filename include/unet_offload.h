@@ -40,7 +40,7 @@ enum unet_verdict {
     UNET_V_DROP_L2_TRUNCATED = 1,    /* frame < 14 B: panic, src/devices/ethernet.rs:50-52 */
     UNET_V_DROP_L2_ETHERTYPE = 2,    /* ethertype not 0x0800/0x0806, src/protocols.rs:33-42 */
     UNET_V_DROP_L2_NOT_FOR_ME = 3,   /* dst MAC neither ours nor ff:ff:ff:ff:ff:ff, src/devices/ethernet.rs:63-71 */
-    UNET_V_PASS_ARP = 4,             /* ethertype 0x0806: goes to the ARP queue on the host, src/protocols.rs:93 */
+    UNET_V_PASS_ARP = 4,             /* valid ARP message whose target is our address: the host caches the sender and replies, src/protocols/arp.rs:238-245 */
     UNET_V_DROP_L3_TRUNCATED = 5,    /* packet < 20 B or IHL*4 > len: panic, src/protocols/ipv4.rs:189-203,415 */
     UNET_V_DROP_L3_PROTO = 6,        /* protocol byte not ICMP/UDP; checked before anything else, src/transport.rs:18-26 via ipv4.rs:189 */
     UNET_V_DROP_L3_VERSION = 7,      /* src/protocols/ipv4.rs:129-133 */
@@ -64,6 +64,13 @@ enum unet_verdict {
     UNET_V_ACCEPT_TCP = 24,
     /* Only produced by unet_ipv4_validate*: header parsed and validate() returned Ok. */
     UNET_V_L3_HEADER_OK = 25,
+    /* ARP messages (ethertype 0x0806, MODE_L2), arp::recv src/protocols/arp.rs:206-246: */
+    UNET_V_DROP_ARP_TRUNCATED = 26,  /* < 28 B after the Ethernet header: panic, arp.rs:211,225 (slices [0..8], [8..28]) */
+    UNET_V_DROP_ARP_HTYPE = 27,      /* hardware type != 1, arp.rs:212-214 */
+    UNET_V_DROP_ARP_PTYPE = 28,      /* protocol type != 0x0800, arp.rs:215-217 */
+    UNET_V_DROP_ARP_HLEN = 29,       /* hardware address length != 6, arp.rs:218-220 */
+    UNET_V_DROP_ARP_PLEN = 30,       /* protocol address length != 4, arp.rs:221-223 */
+    UNET_V_IGNORE_ARP_NOT_FOR_ME = 31,/* valid, target is another host: Ok(()) with no action, arp.rs:238,246 */
     UNET_V_COUNT = 32                /* size of a counter array indexed by verdict */
 };
 

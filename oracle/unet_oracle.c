@@ -230,6 +230,21 @@ oracle_result oracle_ipv4_recv(const uint8_t* data, size_t len, const oracle_ifa
     return tcp_recv_ext(payload, plen, src, dst); /* only reachable with ext_tcp */
 }
 
+/* arp::recv up to its decision, src/protocols/arp.rs:206-246.  ArpHeader::from takes data[0..8]
+ * (:211, panics below 8 bytes); the four field checks follow in order (:212-223); ArpMessage::from
+ * (:225) slices up to byte 28 (panics below 28); a message whose target protocol address is ours makes
+ * the stack cache the sender and reply (:238-245), any other is ignored. */
+static oracle_result arp_recv(const uint8_t* data, size_t len, const oracle_iface* iface) {
+    if (len < 8) return mk(OV_DROP_ARP_TRUNCATED, 0, 0);
+    if (be16(data) != 1) return mk(OV_DROP_ARP_HTYPE, 0, 0);
+    if (be16(data + 2) != 0x0800) return mk(OV_DROP_ARP_PTYPE, 0, 0);
+    if (data[4] != 6) return mk(OV_DROP_ARP_HLEN, 0, 0);
+    if (data[5] != 4) return mk(OV_DROP_ARP_PLEN, 0, 0);
+    if (len < 28) return mk(OV_DROP_ARP_TRUNCATED, 0, 0);
+    if (be32(data + 24) == iface->unicast) return mk(OV_PASS_ARP, 0, 0);
+    return mk(OV_IGNORE_ARP_NOT_FOR_ME, 0, 0);
+}
+
 /* ------------------------------------------------------------ a11 */
 
 /* ethernet::recv, src/devices/ethernet.rs:58-75, then the queue hand-off of
@@ -244,7 +259,7 @@ oracle_result oracle_ethernet_recv(const uint8_t* frame, size_t len, const oracl
     if (memcmp(frame, iface->mac, 6) != 0 && memcmp(frame, bcast, 6) != 0) {
         return mk(OV_DROP_L2_NOT_FOR_ME, 0, 0);
     }
-    if (ethertype == 0x0806) return mk(OV_PASS_ARP, 0, 0);
+    if (ethertype == 0x0806) return arp_recv(frame + 14, len - 14, iface);
     return oracle_ipv4_recv(frame + 14, len - 14, iface);
 }
 

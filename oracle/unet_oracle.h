@@ -50,6 +50,12 @@ enum oracle_verdict {
     OV_DROP_TCP_CSUM = 23,
     OV_ACCEPT_TCP = 24,
     OV_L3_HEADER_OK = 25,
+    OV_DROP_ARP_TRUNCATED = 26,
+    OV_DROP_ARP_HTYPE = 27,
+    OV_DROP_ARP_PTYPE = 28,
+    OV_DROP_ARP_HLEN = 29,
+    OV_DROP_ARP_PLEN = 30,
+    OV_IGNORE_ARP_NOT_FOR_ME = 31,
     OV_COUNT = 32
 };
 

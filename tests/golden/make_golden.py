@@ -43,7 +43,9 @@ V = dict(
     DROP_L3_PROTO=6, DROP_L3_VERSION=7, DROP_L3_IHL_SHORT=8, DROP_L3_IHL_LONG=9, DROP_L3_FRAGMENT=10,
     DROP_L3_CSUM=11, IGNORE_L3_NOT_FOR_ME=12, DROP_ICMP_TRUNCATED=13, DROP_ICMP_TYPE=14, ACCEPT_ICMP_ECHO=15,
     ACCEPT_ICMP_ECHOREPLY=16, DROP_UDP_SHORT=17, DROP_UDP_LEN=18, DROP_UDP_CSUM=19, ACCEPT_UDP=20,
-    DROP_TCP_SHORT=21, DROP_TCP_DOFF=22, DROP_TCP_CSUM=23, ACCEPT_TCP=24, L3_HEADER_OK=25)
+    DROP_TCP_SHORT=21, DROP_TCP_DOFF=22, DROP_TCP_CSUM=23, ACCEPT_TCP=24, L3_HEADER_OK=25,
+    DROP_ARP_TRUNCATED=26, DROP_ARP_HTYPE=27, DROP_ARP_PTYPE=28, DROP_ARP_HLEN=29, DROP_ARP_PLEN=30,
+    IGNORE_ARP_NOT_FOR_ME=31)
 
 
 def hdr_validate(b: bytes, ext_tcp: bool):
@@ -111,6 +113,25 @@ def ipv4_recv(d: bytes, ifc):
     return ("DROP_TCP_CSUM", 6, f) if f else ("ACCEPT_TCP", 6, 0)
 
 
+def arp_recv(d: bytes, ifc):
+    """src/protocols/arp.rs:206-246"""
+    if len(d) < 8:
+        return ("DROP_ARP_TRUNCATED", 0, 0)
+    htype, ptype, hlen, plen = struct.unpack(">HHBB", d[:6])
+    if htype != 1:
+        return ("DROP_ARP_HTYPE", 0, 0)
+    if ptype != 0x0800:
+        return ("DROP_ARP_PTYPE", 0, 0)
+    if hlen != 6:
+        return ("DROP_ARP_HLEN", 0, 0)
+    if plen != 4:
+        return ("DROP_ARP_PLEN", 0, 0)
+    if len(d) < 28:
+        return ("DROP_ARP_TRUNCATED", 0, 0)
+    tpa = struct.unpack(">I", d[24:28])[0]
+    return ("PASS_ARP", 0, 0) if tpa == ifc["unicast"] else ("IGNORE_ARP_NOT_FOR_ME", 0, 0)
+
+
 def eth_recv(fr: bytes, ifc):
     if len(fr) < 14:
         return ("DROP_L2_TRUNCATED", 0, 0)
@@ -120,7 +141,7 @@ def eth_recv(fr: bytes, ifc):
     if fr[:6] != bytes(ifc["mac"]) and fr[:6] != b"\xff" * 6:
         return ("DROP_L2_NOT_FOR_ME", 0, 0)
     if et == 0x0806:
-        return ("PASS_ARP", 0, 0)
+        return arp_recv(fr[14:], ifc)
     return ipv4_recv(fr[14:], ifc)
 
 
@@ -355,8 +376,22 @@ def main():
     assert add("l2_ethertype_checked_before_mac", eth(b"\x02\x01\x02\x03\x04\x05", 0x86DD, good_udp), tap, l2=True) == "DROP_L2_ETHERTYPE"
     assert add("l2_other_mac", eth(b"\x02\x01\x02\x03\x04\x05", 0x0800, good_udp), tap, l2=True) == "DROP_L2_NOT_FOR_ME"
     assert add("l2_mac_differs_in_last_byte", eth(mac[:5] + b"\x31", 0x0800, good_udp), tap, l2=True) == "DROP_L2_NOT_FOR_ME"
-    assert add("l2_arp", eth(b"\xff" * 6, 0x0806, bytes(28)), tap, l2=True) == "PASS_ARP"
-    assert add("l2_arp_other_mac", eth(b"\x02\x01\x02\x03\x04\x05", 0x0806, bytes(28)), tap, l2=True) == "DROP_L2_NOT_FOR_ME"
+    def arp(oper, spa, tpa, htype=1, ptype=0x0800, hlen=6, plen=4):
+        return struct.pack(">HHBBH", htype, ptype, hlen, plen, oper) + b"\x02\xaa\xbb\xcc\xdd\xee" + struct.pack(">I", spa) + bytes(6) + struct.pack(">I", tpa)
+
+    assert add("l2_arp_request_for_me", eth(b"\xff" * 6, 0x0806, arp(1, 0xC0000201, me)), tap, l2=True) == "PASS_ARP"
+    assert add("l2_arp_reply_for_me_padded_to_60", eth(mac, 0x0806, arp(2, 0xC0000201, me) + bytes(18)), tap, l2=True) == "PASS_ARP"
+    assert add("l2_arp_request_for_other_host", eth(b"\xff" * 6, 0x0806, arp(1, 0xC0000201, 0xC0000207)), tap, l2=True) == "IGNORE_ARP_NOT_FOR_ME"
+    assert add("l2_arp_other_mac", eth(b"\x02\x01\x02\x03\x04\x05", 0x0806, arp(1, 0xC0000201, me)), tap, l2=True) == "DROP_L2_NOT_FOR_ME"
+    assert add("l2_arp_htype_6", eth(mac, 0x0806, arp(1, 0xC0000201, me, htype=6)), tap, l2=True) == "DROP_ARP_HTYPE"
+    assert add("l2_arp_ptype_ipv6", eth(mac, 0x0806, arp(1, 0xC0000201, me, ptype=0x86DD)), tap, l2=True) == "DROP_ARP_PTYPE"
+    assert add("l2_arp_hlen_8", eth(mac, 0x0806, arp(1, 0xC0000201, me, hlen=8)), tap, l2=True) == "DROP_ARP_HLEN"
+    assert add("l2_arp_plen_16", eth(mac, 0x0806, arp(1, 0xC0000201, me, plen=16)), tap, l2=True) == "DROP_ARP_PLEN"
+    assert add("l2_arp_htype_checked_before_ptype", eth(mac, 0x0806, arp(1, 0xC0000201, me, htype=2, ptype=1, hlen=1, plen=1)), tap, l2=True) == "DROP_ARP_HTYPE"
+    assert add("l2_arp_truncated_7", eth(mac, 0x0806, arp(1, 0xC0000201, me)[:7]), tap, l2=True) == "DROP_ARP_TRUNCATED"
+    assert add("l2_arp_truncated_27", eth(mac, 0x0806, arp(1, 0xC0000201, me)[:27]), tap, l2=True) == "DROP_ARP_TRUNCATED"
+    assert add("l2_arp_bad_plen_short_buffer", eth(mac, 0x0806, arp(1, 0xC0000201, me, plen=5)[:12]), tap, l2=True) == "DROP_ARP_PLEN"
+    assert add("l2_arp_empty", eth(mac, 0x0806, b""), tap, l2=True) == "DROP_ARP_TRUNCATED"
     assert add("l2_header_only", eth(mac, 0x0800, b""), tap, l2=True) == "DROP_L3_TRUNCATED"
     assert add("l2_jumbo_9000_udp", eth(mac, 0x0800, ip_header(17, other, me, 8 + 8958) + udp_segment(other, me, 9, 10, prng("jumbo", 8958))), tap, l2=True, tail=("jumbo", 8958)) == "ACCEPT_UDP"
 

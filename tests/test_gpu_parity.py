@@ -242,7 +242,7 @@ def test_l2_mode_random_frames(offload, ext_tcp):
     exp = O.recv_batch(a2, o2, l2, ifc2)
     bad = np.nonzero(got != exp)[0]
     assert bad.size == 0, (bad[:5], got[bad[:5]], exp[bad[:5]], l2[bad[:5]])
-    assert {1, 2, 3, 4} <= set(exp["verdict"].tolist())
+    assert {1, 2, 3} <= set(exp["verdict"].tolist()) and set(exp["verdict"].tolist()) & {26, 27, 28, 29, 30}
 
 
 def test_mutated_records_against_oracle(offload):

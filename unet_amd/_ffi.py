@@ -47,6 +47,12 @@ class Verdict(enum.IntEnum):
     DROP_TCP_CSUM = 23
     ACCEPT_TCP = 24
     L3_HEADER_OK = 25
+    DROP_ARP_TRUNCATED = 26
+    DROP_ARP_HTYPE = 27
+    DROP_ARP_PTYPE = 28
+    DROP_ARP_HLEN = 29
+    DROP_ARP_PLEN = 30
+    IGNORE_ARP_NOT_FOR_ME = 31
 
 
 V_COUNT = 32

@@ -1,7 +1,6 @@
-// Header parse + verdict logic of the receive path, written once and instantiated for
-//  * a wave-cooperative caller (header dwords come out of another lane's registers through
-//    v_readlane, so every value here is wave-uniform and the compiler keeps it on the scalar unit)
-//  * a lane-per-record caller (header dwords are plain per-lane loads).
+// Header parse + verdict logic of the receive path, written once over an abstract "dword k of the
+// record" fetch: the kernels run it lane-parallel on headers parked in LDS (one lane per record),
+// the flow-hash kernel on plain per-lane global loads.
 // The order of checks is the reference's order; each block cites the lines it restates.
 #pragma once
 #include "csum_core.h"
@@ -36,6 +35,12 @@ enum : u32 {
     V_DROP_TCP_CSUM = 23,
     V_ACCEPT_TCP = 24,
     V_L3_HEADER_OK = 25,
+    V_DROP_ARP_TRUNCATED = 26,
+    V_DROP_ARP_HTYPE = 27,
+    V_DROP_ARP_PTYPE = 28,
+    V_DROP_ARP_HLEN = 29,
+    V_DROP_ARP_PLEN = 30,
+    V_IGNORE_ARP_NOT_FOR_ME = 31,
     V_COUNT = 32
 };
 
@@ -106,7 +111,20 @@ __device__ __forceinline__ Parsed parse_record(const F& f, u32 flen, const Iface
         const bool mine = d0 == ifc.mac_lo && (d1 & 0xffffu) == ifc.mac_hi;
         const bool bcast = d0 == 0xffffffffu && (d1 & 0xffffu) == 0xffffu;
         if (!mine && !bcast) { P.res = pack_result(V_DROP_L2_NOT_FOR_ME, 0, 0); return P; }  // :63-71
-        if (ethertype == 0x0806u) { P.res = pack_result(V_PASS_ARP, 0, 0); return P; }
+        if (ethertype == 0x0806u) {
+            // arp::recv, src/protocols/arp.rs:206-246: header checks in order, then "is the target us?"
+            const u32 alen = flen - 14u;
+            if (alen < 8u) { P.res = pack_result(V_DROP_ARP_TRUNCATED, 0, 0); return P; }       // [0..8] panics, :211
+            const u32 a0 = l3raw<MODE>(f, 0), a1 = l3raw<MODE>(f, 4);  // ARP bytes 0..7 (same 14-byte skew as IPv4)
+            if (bswap16(a0 & 0xffffu) != 1u) { P.res = pack_result(V_DROP_ARP_HTYPE, 0, 0); return P; }       // :212-214
+            if (bswap16(a0 >> 16) != 0x0800u) { P.res = pack_result(V_DROP_ARP_PTYPE, 0, 0); return P; }      // :215-217
+            if ((a1 & 0xffu) != 6u) { P.res = pack_result(V_DROP_ARP_HLEN, 0, 0); return P; }                 // :218-220
+            if (((a1 >> 8) & 0xffu) != 4u) { P.res = pack_result(V_DROP_ARP_PLEN, 0, 0); return P; }          // :221-223
+            if (alen < 28u) { P.res = pack_result(V_DROP_ARP_TRUNCATED, 0, 0); return P; }      // ArpMessage::from, :225
+            const u32 tpa = bswap32(l3raw<MODE>(f, 24));
+            P.res = pack_result(tpa == ifc.unicast ? V_PASS_ARP : V_IGNORE_ARP_NOT_FOR_ME, 0, 0);              // :238-246
+            return P;
+        }
         l3len = flen - 14u;  // everything after the header, padding included (:73)
         l2sum = halves(d0) + halves(d1) + halves(d2) + (d3 & 0xffffu);
     }
