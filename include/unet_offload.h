@@ -183,6 +183,44 @@ int unet_generate_dev(unet_ctx* ctx, void* stream, uint8_t* d_arena, uint64_t ar
 int unet_generate(unet_ctx* ctx, uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16,
                   uint32_t stride16, const uint32_t* len, uint32_t n, uint8_t* status);
 
+/* ------------- transmit path, whole packets: udp::send / icmp::send -> ipv4::send -> tap::send */
+/* One packet to build.  `src` is the address the caller passed to udp::send / icmp::send (it goes into
+ * the UDP pseudo-header, src/transport/udp.rs:186-192); the IPv4 header always carries the interface's
+ * unicast address (src/protocols/ipv4.rs:338, create_ip_header's `src` argument). */
+typedef struct unet_tx_desc {
+    uint32_t src;        /* Endpoint address given to the send call (0.0.0.0 or the interface address) */
+    uint32_t dst;        /* destination IPv4 address */
+    uint16_t l4a;        /* UDP: source port.  ICMP: type << 8 | code */
+    uint16_t l4b;        /* UDP: destination port.  ICMP: unused */
+    uint32_t values;     /* ICMP: the 4 bytes after the checksum (identifier, sequence).  UDP: unused */
+    uint16_t ip_id;      /* identification, Ipv4IdGenerator::next() (src/protocols/ipv4.rs:292-296) */
+    uint8_t proto;       /* 1 (ICMP) or 17 (UDP) */
+    uint8_t reserved0;
+    uint8_t dst_mac[6];  /* MODE_L2 only: resolved by the host (ARP cache) or ff:ff:ff:ff:ff:ff */
+    uint8_t reserved1[2];
+} unet_tx_desc;          /* 28 bytes */
+
+#define UNET_TX_OK 0
+#define UNET_TX_E_PROTO 1     /* proto not 1/17 */
+#define UNET_TX_E_TOO_LONG 2  /* payload > 65535 - 20 - 8 (src/transport/udp.rs:174-180) */
+#define UNET_TX_E_RANGE 3     /* payload or output record outside its arena */
+
+/* Builds packet i = [Ethernet header (MODE_L2)] IPv4 header (IHL 5, ttl 64, flags 0) | UDP or ICMP header |
+ * payload i, with every checksum the reference computes on this path:
+ *   UDP  hdr(cksum 0)||payload seeded with the pseudo-header, no 0->0xffff substitution (udp.rs:181-203)
+ *   ICMP hdr(cksum 0)||data (icmp.rs:75-85);  IPv4 header (ipv4.rs:366-391)
+ * MODE_L2 adds dst MAC | iface->mac | 0x0800 and pads like tap::send: when the L3 packet is shorter than
+ * 60 bytes, zero bytes are appended until IT is 60 bytes long -- the frame is then 74 bytes
+ * (src/driver/tap.rs:138-152 pads data.len(), not the frame).
+ * Payload i is record i of the payload arena (same layout rules as every other arena); packet i is
+ * written at 16*d_out_off16[i] of the output arena, its length to d_out_len[i] (28 + payload, or
+ * 14 + max(28 + payload, 60)), its status (UNET_TX_*) to d_status[i] (may be NULL).  The host computes
+ * d_out_off16 from the payload lengths; routing, the MTU check and ARP resolution stay on the host. */
+int unet_tx_build_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload_arena, uint64_t payload_arena_bytes,
+                      const uint32_t* d_payload_off16, uint32_t payload_stride16, const uint32_t* d_payload_len,
+                      const unet_tx_desc* d_desc, uint32_t n, const unet_iface* iface, uint8_t* d_out_arena,
+                      uint64_t out_arena_bytes, const uint32_t* d_out_off16, uint32_t* d_out_len, uint8_t* d_status);
+
 /* ------------------------------------------------------------ counters */
 /* Histogram of verdicts: d_counts[v] += number of results with verdict v (UNET_V_COUNT
  * u64 slots, caller zeroes them).  The reference keeps no counters; these are what a

@@ -67,6 +67,8 @@ def lib():
         L.oracle_ipv4_validate_batch.argtypes = [vp, C.c_uint32, C.c_int, vp]
         L.oracle_generate_batch.restype = None
         L.oracle_generate_batch.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, vp]
+        L.oracle_tx_build_batch.restype = None
+        L.oracle_tx_build_batch.argtypes = [vp, vp, C.c_uint32, vp, vp, C.c_uint32, C.POINTER(IfaceC), vp, vp, vp, vp]
         L.oracle_flow_hash5.restype = C.c_uint32
         L.oracle_flow_hash5.argtypes = [C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint16, C.c_uint16]
         L.oracle_flow_hash_record.restype = C.c_uint32
@@ -172,6 +174,27 @@ def create_ip_header(ident: int, protocol: int, src: int, dst: int, data_len: in
     buf = C.create_string_buffer(20)
     lib().oracle_create_ip_header(ident, protocol, src, dst, data_len, buf)
     return buf.raw
+
+
+def tx_build_batch(pay_arena: np.ndarray, pay_off16, pay_lens: np.ndarray, desc: np.ndarray, iface, out_off16: np.ndarray,
+                   out_bytes: int, pay_stride16: int = 0, fill: int = 0):
+    """Returns (out_arena, out_len, status); bytes the oracle does not write keep `fill`."""
+    pay_arena = np.ascontiguousarray(pay_arena, dtype=np.uint8)
+    pay_lens = np.ascontiguousarray(pay_lens, dtype=np.uint32)
+    if pay_off16 is not None:
+        pay_off16 = np.ascontiguousarray(pay_off16, dtype=np.uint32)
+    out_off16 = np.ascontiguousarray(out_off16, dtype=np.uint32)
+    desc = np.ascontiguousarray(desc)
+    assert desc.dtype.itemsize == 28
+    n = len(pay_lens)
+    out = np.full(out_bytes + 64, fill, dtype=np.uint8)
+    out_len = np.zeros(n, dtype=np.uint32)
+    status = np.zeros(n, dtype=np.uint8)
+    ic = iface_c(iface)
+    lib().oracle_tx_build_batch(pay_arena.ctypes.data, None if pay_off16 is None else pay_off16.ctypes.data, pay_stride16,
+                                pay_lens.ctypes.data, desc.ctypes.data, n, C.byref(ic), out.ctypes.data, out_off16.ctypes.data,
+                                out_len.ctypes.data, status.ctypes.data)
+    return out[:out_bytes], out_len, status
 
 
 def flow_hash5(src, dst, proto, sport, dport) -> int:

@@ -349,6 +349,50 @@ uint8_t oracle_generate(uint8_t* pkt, size_t len) {
     return 0;
 }
 
+/* One whole transmitted packet: udp::send (udp.rs:168-216) or icmp::send (icmp.rs:66-95) ->
+ * ipv4::send (ipv4.rs:300-364: the header's source is interface.unicast) -> in L2 mode the Ethernet
+ * header and tap::send's padding (tap.rs:138-152: zero bytes until the L3 packet -- not the frame --
+ * is 60 bytes long).  Returns the number of bytes written to out (0 with *status != 0 otherwise).
+ * Payloads over 65535-20-8 bytes are refused for both protocols: UDP by udp.rs:174-180; for ICMP the
+ * reference would let `total_length as u16` wrap (ipv4.rs:373), which this build reports instead. */
+uint32_t oracle_tx_build(const oracle_tx_desc* d, const uint8_t* payload, size_t plen, const oracle_iface* iface,
+                         uint8_t* out, uint8_t* status) {
+    uint8_t st = 0;
+    if (!(d->proto == 1 || d->proto == 17)) st = 1;
+    else if (plen > 65535u - 20u - 8u) st = 2;
+    if (status) *status = st;
+    if (st) return 0;
+    uint8_t* p = out;
+    if (iface->mode == 1) {
+        memcpy(p, d->dst_mac, 6);                                                 /* tap.rs:138-142 */
+        memcpy(p + 6, iface->mac, 6);
+        p[12] = 0x08;
+        p[13] = 0x00;
+        p += 14;
+    }
+    size_t l4len = 8 + plen;
+    oracle_create_ip_header(d->ip_id, d->proto, iface->unicast, d->dst, l4len, p); /* ipv4.rs:337-339 */
+    uint8_t* l4 = p + 20;
+    if (d->proto == 17) {
+        put_be16(l4, d->l4a);
+        put_be16(l4 + 2, d->l4b);
+        put_be16(l4 + 4, (uint16_t)l4len);
+        put_be16(l4 + 6, oracle_udp_send_checksum(d->src, d->dst, d->l4a, d->l4b, payload, plen));
+    } else {
+        l4[0] = (uint8_t)(d->l4a >> 8);
+        l4[1] = (uint8_t)(d->l4a & 0xff);
+        put_be16(l4 + 2, oracle_icmp_send_checksum(l4[0], l4[1], d->values, payload, plen));
+        put_be32(l4 + 4, d->values);
+    }
+    if (plen) memcpy(l4 + 8, payload, plen);
+    size_t l3len = 20 + l4len;
+    if (iface->mode == 1 && l3len < 60) {                                         /* tap.rs:147-152 */
+        memset(p + l3len, 0, 60 - l3len);
+        l3len = 60;
+    }
+    return (uint32_t)((size_t)(p - out) + l3len);
+}
+
 /* ------------------------------------------------------------ batches */
 
 static const uint8_t* rec_ptr(const uint8_t* arena, const uint32_t* off16, uint32_t stride16, uint32_t i) {
@@ -389,6 +433,17 @@ void oracle_generate_batch(uint8_t* arena, const uint32_t* off16, uint32_t strid
     for (uint32_t i = 0; i < n; i++) {
         uint8_t s = oracle_generate((uint8_t*)rec_ptr(arena, off16, stride16, i), len[i]);
         if (status) status[i] = s;
+    }
+}
+
+void oracle_tx_build_batch(const uint8_t* pay_arena, const uint32_t* pay_off16, uint32_t pay_stride16,
+                           const uint32_t* pay_len, const oracle_tx_desc* desc, uint32_t n, const oracle_iface* iface,
+                           uint8_t* out_arena, const uint32_t* out_off16, uint32_t* out_len, uint8_t* status) {
+    for (uint32_t i = 0; i < n; i++) {
+        uint8_t st = 0;
+        out_len[i] = oracle_tx_build(&desc[i], rec_ptr(pay_arena, pay_off16, pay_stride16, i), pay_len[i], iface,
+                                     out_arena + (size_t)out_off16[i] * 16u, &st);
+        if (status) status[i] = st;
     }
 }
 

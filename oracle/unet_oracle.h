@@ -105,6 +105,24 @@ void oracle_create_ip_header(uint16_t id, uint8_t protocol, uint32_t src, uint32
  * returns 0 if filled, else the drop code explaining why the record was left alone. */
 uint8_t oracle_generate(uint8_t* pkt, size_t len);
 
+/* Same layout as unet_tx_desc in include/unet_offload.h (a test asserts the size). */
+typedef struct oracle_tx_desc {
+    uint32_t src, dst;
+    uint16_t l4a, l4b;
+    uint32_t values;
+    uint16_t ip_id;
+    uint8_t proto, reserved0;
+    uint8_t dst_mac[6];
+    uint8_t reserved1[2];
+} oracle_tx_desc;
+/* udp::send / icmp::send -> ipv4::send -> (L2) ethernet header + tap::send padding, one packet:
+ * src/transport/udp.rs:168-216, icmp.rs:66-95, src/protocols/ipv4.rs:300-391, src/driver/tap.rs:138-152 */
+uint32_t oracle_tx_build(const oracle_tx_desc* d, const uint8_t* payload, size_t plen, const oracle_iface* iface,
+                         uint8_t* out, uint8_t* status);
+void oracle_tx_build_batch(const uint8_t* pay_arena, const uint32_t* pay_off16, uint32_t pay_stride16,
+                           const uint32_t* pay_len, const oracle_tx_desc* desc, uint32_t n, const oracle_iface* iface,
+                           uint8_t* out_arena, const uint32_t* out_off16, uint32_t* out_len, uint8_t* status);
+
 /* Batch drivers (single thread), used for parity sweeps and as the timed CPU baseline.
  * Record i starts at 16*off16[i] (or i*16*stride16 when off16 is NULL). */
 void oracle_recv_batch(const uint8_t* arena, const uint32_t* off16, uint32_t stride16,

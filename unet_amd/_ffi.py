@@ -105,6 +105,27 @@ class Iface:
         return o
 
 
+# unet_tx_desc, 28 bytes
+TX_DESC_DTYPE = np.dtype([("src", "<u4"), ("dst", "<u4"), ("l4a", "<u2"), ("l4b", "<u2"), ("values", "<u4"), ("ip_id", "<u2"),
+                          ("proto", "u1"), ("reserved0", "u1"), ("dst_mac", "u1", (6,)), ("reserved1", "u1", (2,))])
+TX_OK, TX_E_PROTO, TX_E_TOO_LONG, TX_E_RANGE = 0, 1, 2, 3
+
+
+def tx_frame_len(payload_len, mode: int):
+    """Length of the packet unet_tx_build_dev writes for a payload: 28 + payload in L3 mode; in L2 mode the
+    Ethernet header plus the L3 packet padded to 60 bytes (src/driver/tap.rs:147-152)."""
+    l3 = np.asarray(payload_len, dtype=np.int64) + 28
+    return l3 if mode == 0 else 14 + np.maximum(l3, 60)
+
+
+def tx_out_layout(payload_len, mode: int):
+    """(out_off16, out_arena_bytes) for packing the built packets back to back on 16-byte boundaries."""
+    slots = (tx_frame_len(payload_len, mode) + 15) // 16
+    off16 = np.zeros(len(slots), dtype=np.int64)
+    np.cumsum(slots[:-1], out=off16[1:])
+    return off16.astype(np.uint32), int(max(16, 16 * int(slots.sum())))
+
+
 _lib = None
 
 _vp, _u8p, _u16p, _u32p, _u64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
@@ -124,6 +145,8 @@ _SIGS = {
     "unet_verify": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
     "unet_generate_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, _u8p]),
     "unet_generate": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, _u8p]),
+    "unet_tx_build_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, _vp, C.c_uint32, C.POINTER(_IfaceC), _u8p,
+                                    C.c_uint64, _u32p, _u32p, _u8p]),
     "unet_count_verdicts_dev": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _u64p]),
     "unet_flow_hash5": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint16, C.c_uint16]),
     "unet_flow_hash_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _u32p]),
@@ -329,6 +352,12 @@ class Offload:
 
     def generate_dev(self, d_arena, arena_bytes, d_off16, stride16, d_len, n, d_status, stream=None):
         _check(self.lib.unet_generate_dev(self.h, stream, d_arena, arena_bytes, d_off16, stride16, d_len, n, d_status))
+
+    def tx_build_dev(self, d_pay_arena, pay_bytes, d_pay_off16, pay_stride16, d_pay_len, d_desc, n, iface: Iface, d_out_arena,
+                     out_bytes, d_out_off16, d_out_len, d_status, stream=None):
+        ic = iface.c()
+        _check(self.lib.unet_tx_build_dev(self.h, stream, d_pay_arena, pay_bytes, d_pay_off16, pay_stride16, d_pay_len, d_desc, n,
+                                          C.byref(ic), d_out_arena, out_bytes, d_out_off16, d_out_len, d_status))
 
     def count_verdicts_dev(self, d_results, n, d_counts, stream=None):
         _check(self.lib.unet_count_verdicts_dev(self.h, stream, d_results, n, d_counts))

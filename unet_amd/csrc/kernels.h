@@ -9,6 +9,7 @@
 namespace unetdev {
 
 constexpr u32 kBlock = 256;      // 4 waves
+constexpr u32 UNET_TX_OK_ = 0, UNET_TX_E_PROTO_ = 1, UNET_TX_E_TOO_LONG_ = 2, UNET_TX_E_RANGE_ = 3;  // = UNET_TX_* of the C header
 constexpr u32 kMaxLen = 65535;   // IPv4 maximum (src/protocols/ipv4.rs:18), loopback MTU (src/devices/loopback.rs:16)
 
 // Where the records of a batch live.
@@ -156,6 +157,29 @@ __device__ __forceinline__ u32 stream_one(const Rows2& cur, u32 lane, u32x4* __r
     }
     return wave_sum(acc);
 }
+
+// Wave-uniform byte masks for the cut last chunk (index nch - 1) of a buffer of `flen` bytes.
+struct TailMask {
+    u32 last;
+    u32 m0, m1, m2, m3;
+    __device__ __forceinline__ TailMask(u32 flen, u32 nch) {
+        last = nch - 1u;
+        const int tb = (int)(flen - last * 16u);  // 1..16 valid bytes in the last chunk (16 when nch == 0)
+        m0 = keep_bytes(tb);
+        m1 = keep_bytes(tb - 4);
+        m2 = keep_bytes(tb - 8);
+        m3 = keep_bytes(tb - 12);
+    }
+    __device__ __forceinline__ u32x4 apply(u32x4 v, u32 chunk) const {
+        if (chunk == last) {
+            v.x &= m0;
+            v.y &= m1;
+            v.z &= m2;
+            v.w &= m3;
+        }
+        return v;
+    }
+};
 
 // Per-lane byte masks of a record's cut last chunk: keep the first (flen & 15) bytes.
 struct LaneTail {
@@ -419,6 +443,149 @@ rec[0] = u32x4{w0, w1, (w2 & 0xffffu) | (bswap16(finish(hdr)) << 16), w3};
         }
     }
     if (status && t.lane < t.cnt) status[t.first + t.lane] = (uint8_t)st;
+}
+
+// ------------------- transmit path, whole packets: udp::send / icmp::send -> ipv4::send -> tap::send
+struct TxDesc {  // mirrors unet_tx_desc (28 bytes, 4-byte aligned)
+    u32 src, dst;
+    u32 l4ab;      // l4a | l4b << 16
+    u32 values;
+    u32 id_proto;  // ip_id | proto << 16
+    u32 mac_lo;    // dst_mac[0..3]
+    u32 mac_hi;    // dst_mac[4..5]
+};
+static_assert(sizeof(TxDesc) == 28, "descriptor layout");
+
+// 16 output bytes = bytes R..15 of `lo` followed by bytes 0..R-1 of `hi` (R = 4 or 6).
+template <int R>
+__device__ __forceinline__ u32x4 splice(u32x4 lo, u32x4 hi) {
+    if (R == 4) return u32x4{lo.y, lo.z, lo.w, hi.x};
+    return u32x4{(lo.y >> 16) | (lo.z << 16), (lo.z >> 16) | (lo.w << 16), (lo.w >> 16) | (hi.x << 16),
+                 (hi.x >> 16) | (hi.y << 16)};
+}
+
+// MODE_L3: packet = 28 header bytes + payload.  MODE_L2: 42 header bytes + payload (+ tap::send's pad).
+// Phase A, wave-cooperative per packet: the payload is read once in 16-byte chunks, summed, and stored
+// shifted by the header size (every output chunk splices two neighbouring input chunks).
+// Phase B, lane-parallel: lane j builds packet j's headers -- all checksums included -- and stores the
+// first 32 (48) bytes, which also hold the first 4 (6) payload bytes.
+template <int MODE, int TILE>
+__global__ __launch_bounds__(kBlock) void k_tx_build(Batch pay, const TxDesc* __restrict__ desc, IfaceDev ifc,
+                                                     uint8_t* __restrict__ out_arena, u64 out_bytes,
+                                                     const u32* __restrict__ out_off16, u32* __restrict__ out_len,
+                                                     uint8_t* __restrict__ status) {
+    constexpr u32 H = MODE == MODE_L2 ? 42u : 28u;   // header bytes in front of the payload
+    constexpr u32 SH = MODE == MODE_L2 ? 3u : 2u;    // output chunks that contain header bytes
+    constexpr int R = MODE == MODE_L2 ? 6 : 4;       // payload bytes inside the last header chunk
+    static_assert(16u * SH - H == (u32)R, "header geometry");
+    Tile t;
+    if (!t.init<TILE>(pay)) return;
+    const u32 i = t.first + t.lane;
+    TxDesc d = {};
+    u32 my_oslot = 0;
+    if (t.lane < t.cnt) {
+        d = desc[i];
+        my_oslot = out_off16[i];
+    }
+    const u32 proto = (d.id_proto >> 16) & 0xffu;
+    const u32 l3len = 28u + t.my_len;
+    u32 frame_len = MODE == MODE_L2 ? 14u + max(l3len, 60u) : l3len;  // src/driver/tap.rs:147-152
+    u32 st = UNET_TX_OK_;
+    if (!t.my_ok) st = UNET_TX_E_RANGE_;
+    else if (!(proto == 1u || proto == 17u)) st = UNET_TX_E_PROTO_;
+    else if (t.my_len > 65535u - 20u - 8u) st = UNET_TX_E_TOO_LONG_;  // src/transport/udp.rs:174-180
+    else if ((u64)my_oslot * 16u + (((u64)frame_len + 15u) & ~15ull) > out_bytes) st = UNET_TX_E_RANGE_;
+    const bool my_go = t.lane < t.cnt && st == UNET_TX_OK_;
+
+    // ---- phase A
+    u32 my_total = 0;
+    u64 todo = __ballot(my_go);
+    while (todo != 0ull) {
+        const u32 j = (u32)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const u32 plen = rdlane(t.my_len, j), flen = rdlane(frame_len, j);
+        const u32x4* pin = reinterpret_cast<const u32x4*>(pay.arena + (u64)rdlane(t.my_slot, j) * 16u);
+        u32x4* pout = reinterpret_cast<u32x4*>(out_arena + (u64)rdlane(my_oslot, j) * 16u);
+        const u32 nin = (plen + 15u) >> 4, nout = (flen + 15u) >> 4;
+        const TailMask tm(plen, nin);  // uniform masks for the payload's cut last chunk
+        const u32 kend = max(nin, nout - SH);
+        u32 acc = 0;
+        for (u32 k0 = 0; k0 < kend; k0 += kWave) {
+            const u32 k = k0 + t.lane;
+            u32x4 lo = {0, 0, 0, 0}, hi = lo;
+            if (k < nin) lo = tm.apply(ld_row(pin + k), k);
+            if (k + 1u < nin) hi = tm.apply(pin[k + 1u], k + 1u);
+            acc = sum_chunk(lo, acc);
+            if (k + SH < nout) __builtin_nontemporal_store(splice<R>(lo, hi), pout + k + SH);
+        }
+        const u32 total = wave_sum(acc);
+        if (t.lane == j) my_total = total;
+    }
+
+    // ---- phase B: headers as big-endian 16-bit words, checksums in that domain
+    if (my_go) {
+        const u32x4* pin = reinterpret_cast<const u32x4*>(pay.arena + (u64)t.my_slot * 16u);
+        u32x4 in0 = {0, 0, 0, 0};
+        if (t.my_len != 0u) {
+            const LaneTail lt(t.my_len);
+            in0 = pin[0];
+            if (t.my_len < 16u) in0 = lt.apply(in0);
+        }
+        const u32 pay_be = bswap16(fold16(my_total));  // payload's folded sum, big-endian domain
+        const u32 src = ifc.unicast, dst = d.dst;
+        // create_ip_header, src/protocols/ipv4.rs:366-391
+        const u32 ip[10] = {0x4500u, (20u + (8u + t.my_len)) & 0xffffu, d.id_proto & 0xffffu, 0u, (64u << 8) | proto, 0u,
+                            src >> 16, src & 0xffffu, dst >> 16, dst & 0xffffu};
+        u32 ipsum = 0;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) ipsum += ip[q];
+        const u32 ipck = (~fold16(ipsum)) & 0xffffu;
+        u32 l4[4];
+        if (proto == 17u) {
+            // udp::send, src/transport/udp.rs:181-203: pseudo-header uses the caller's src address
+            const u32 length = (8u + t.my_len) & 0xffffu;
+            const u32 pseudo = (d.src >> 16) + (d.src & 0xffffu) + (dst >> 16) + (dst & 0xffffu) + 17u + length;
+            l4[0] = d.l4ab & 0xffffu;
+            l4[1] = d.l4ab >> 16;
+            l4[2] = length;
+            l4[3] = (~fold16(pseudo + l4[0] + l4[1] + l4[2] + pay_be)) & 0xffffu;
+        } else {
+            // icmp::send, src/transport/icmp.rs:75-85
+            l4[0] = d.l4ab & 0xffffu;  // type << 8 | code
+            l4[2] = d.values >> 16;
+            l4[3] = d.values & 0xffffu;
+            l4[1] = (~fold16(l4[0] + l4[2] + l4[3] + pay_be)) & 0xffffu;
+        }
+        // little-endian halves of the wire bytes
+        u32 h[24];
+        int n = 0;
+        if (MODE == MODE_L2) {
+            h[n++] = d.mac_lo & 0xffffu;
+            h[n++] = d.mac_lo >> 16;
+            h[n++] = d.mac_hi & 0xffffu;
+            h[n++] = ifc.mac_lo & 0xffffu;
+            h[n++] = ifc.mac_lo >> 16;
+            h[n++] = ifc.mac_hi & 0xffffu;
+            h[n++] = 0x0008u;  // 08 00
+        }
+#pragma unroll
+        for (int q = 0; q < 10; ++q) h[n++] = bswap16(q == 5 ? ipck : ip[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h[n++] = bswap16(l4[q]);
+        h[n++] = in0.x & 0xffffu;
+        h[n++] = in0.x >> 16;
+        if (MODE == MODE_L2) h[n++] = in0.y & 0xffffu;
+        u32x4* pout = reinterpret_cast<u32x4*>(out_arena + (u64)my_oslot * 16u);
+#pragma unroll
+        for (u32 c = 0; c < SH; ++c) {
+            pout[c] = u32x4{h[8 * c] | (h[8 * c + 1] << 16), h[8 * c + 2] | (h[8 * c + 3] << 16),
+                            h[8 * c + 4] | (h[8 * c + 5] << 16), h[8 * c + 6] | (h[8 * c + 7] << 16)};
+        }
+    }
+    if (t.lane < t.cnt) {
+        out_len[i] = st == UNET_TX_OK_ ? frame_len : 0u;
+        if (status) status[i] = (uint8_t)st;
+    }
 }
 
 // ------------------------------------------------------------------ verdict histogram

@@ -419,6 +419,32 @@ int unet_generate(unet_ctx* c, uint8_t* arena, uint64_t arena_bytes, const uint3
     return d2h_sync(c, arena, c->d_arena.p, arena_bytes);
 }
 
+int unet_tx_build_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload_arena, uint64_t payload_arena_bytes,
+                      const uint32_t* d_payload_off16, uint32_t payload_stride16, const uint32_t* d_payload_len,
+                      const unet_tx_desc* d_desc, uint32_t n, const unet_iface* iface, uint8_t* d_out_arena,
+                      uint64_t out_arena_bytes, const uint32_t* d_out_off16, uint32_t* d_out_len, uint8_t* d_status) {
+    static_assert(sizeof(unet_tx_desc) == sizeof(TxDesc), "descriptor layout");
+    static_assert(UNET_TX_E_PROTO == UNET_TX_E_PROTO_ && UNET_TX_E_TOO_LONG == UNET_TX_E_TOO_LONG_ && UNET_TX_E_RANGE == UNET_TX_E_RANGE_, "status codes");
+    int rc = check_batch(ctx, d_payload_arena, d_payload_off16, payload_stride16, d_payload_len, n);
+    if (rc) return rc;
+    if (n == 0) return UNET_OK;
+    if (!d_desc || !iface || !d_out_arena || !d_out_off16 || !d_out_len) return fail(UNET_E_INVAL, "null argument");
+    if (((uintptr_t)d_out_arena & 15u) != 0) return fail(UNET_E_INVAL, "output arena must be 16-byte aligned");
+    if (iface->mode != UNET_MODE_L3 && iface->mode != UNET_MODE_L2) return fail(UNET_E_INVAL, "bad iface mode %d", iface->mode);
+    HIP_TRY(hipSetDevice(ctx->device));
+    Batch b{d_payload_arena, payload_arena_bytes, d_payload_off16, payload_stride16, d_payload_len, n};
+    const IfaceDev ifc = to_dev(iface);
+    constexpr int T = 16;
+    if (iface->mode == UNET_MODE_L2)
+        hipLaunchKernelGGL((k_tx_build<MODE_L2, T>), dim3(tiles_grid(n, T)), dim3(kBlock), 0, pick(ctx, stream), b, (const TxDesc*)d_desc,
+                           ifc, d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status);
+    else
+        hipLaunchKernelGGL((k_tx_build<MODE_L3, T>), dim3(tiles_grid(n, T)), dim3(kBlock), 0, pick(ctx, stream), b, (const TxDesc*)d_desc,
+                           ifc, d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status);
+    HIP_TRY(hipGetLastError());
+    return UNET_OK;
+}
+
 /* ---------------------------------------------------------------- counters */
 
 int unet_count_verdicts_dev(unet_ctx* ctx, void* stream, const unet_result* d_results, uint32_t n, uint64_t* d_counts) {
