@@ -45,6 +45,7 @@ WORKLOADS = {
     # the other entry points over the udp1500 batch
     "csum": (unet_amd.SYNTH_UDP1500, 1 << 22, 94),
     "generate": (unet_amd.SYNTH_UDP1500, 1 << 22, 94),
+    "txbuild": (unet_amd.SYNTH_UDP1500, 1 << 22, 94),
 }
 DESCRIPTION = {
     "udp1500": "4,194,304 x 1500-byte IPv4/UDP packets per GPU (BASELINE configs[2])",
@@ -53,6 +54,7 @@ DESCRIPTION = {
     "trace": "flow-table trace (2^20 flows, IMIX sizes) generated in HBM in chunks of 16,777,216 records per GPU (BASELINE configs[4])",
     "csum": "calculate_checksum over 4,194,304 x 1500-byte records per GPU (unet_csum_batch_dev)",
     "generate": "transmit-side checksum fill of 4,194,304 x 1500-byte IPv4/UDP packets per GPU, in place (unet_generate_dev)",
+    "txbuild": "4,194,304 x 1500-byte IPv4/UDP packets per GPU built from 1472-byte payloads + descriptors (unet_tx_build_dev)",
 }
 
 
@@ -142,6 +144,25 @@ class Batch:
             self.alg_bytes -= 2 * self.n      # 2-byte results
         elif op == "generate":
             self.alg_bytes += self.n          # 4 bytes of checksum fields + 1 status byte instead of a 4-byte result
+        elif op == "txbuild":
+            # the resident records serve as 1472-byte payloads; every packet goes to one receiver address
+            from unet_amd._ffi import TX_DESC_DTYPE
+            self.rx = unet_amd.Iface("198.51.100.7", "255.255.255.0")
+            desc = np.zeros(self.n, dtype=TX_DESC_DTYPE)
+            rng = np.random.default_rng(SEED + first_idx)
+            desc["src"], desc["dst"], desc["proto"] = ifc.unicast, self.rx.unicast, 17
+            desc["l4a"] = rng.integers(0, 65536, size=self.n)
+            desc["l4b"] = rng.integers(0, 65536, size=self.n)
+            desc["ip_id"] = np.arange(self.n) & 0xFFFF
+            self.desc = torch.from_numpy(desc.view(np.uint8).reshape(-1)).cuda()
+            self.plen = torch.full((self.n,), 1472, dtype=torch.int32, device="cuda")
+            self.ooff = (torch.arange(self.n, dtype=torch.int64, device="cuda") * 94).to(torch.int32)
+            self.out_bytes = self.n * 94 * 16
+            self.out_arena = torch.zeros(self.out_bytes + 16, dtype=torch.uint8, device="cuda")
+            self.olen = torch.zeros(self.n, dtype=torch.int32, device="cuda")
+            self.status = torch.zeros(self.n, dtype=torch.uint8, device="cuda")
+            # payload + packet + descriptor + payload length, output offset, output length, status
+            self.alg_bytes = self.n * (1472 + 1500 + 28 + 4 + 4 + 4 + 1)
 
     def run(self):
         if self.op == "csum":
@@ -152,6 +173,10 @@ class Batch:
             off_ptr = None if self.stride16 else self.off.data_ptr()
             self.ctx.generate_dev(self.arena.data_ptr(), self.nbytes, off_ptr, self.stride16, self.len.data_ptr(), self.n,
                                   self.out.data_ptr(), self.stream)
+        elif self.op == "txbuild":
+            self.ctx.tx_build_dev(self.arena.data_ptr(), self.nbytes, None, 94, self.plen.data_ptr(), self.desc.data_ptr(), self.n,
+                                  self.ifc, self.out_arena.data_ptr(), self.out_bytes, self.ooff.data_ptr(), self.olen.data_ptr(),
+                                  self.status.data_ptr(), self.stream)
         elif self.kind == unet_amd.SYNTH_IPV4_HDR20:
             self.ctx.ipv4_validate_dev(self.arena.data_ptr(), self.n, self.ifc, self.out.data_ptr(), self.stream)
         else:
@@ -290,10 +315,10 @@ def main():
     # rotated over several distinct batches (consecutive index ranges of the same trace) so that no
     # launch finds its input in cache.
     rotate = args.rotate if args.rotate else (6 if kind == unet_amd.SYNTH_IPV4_HDR20 else 1)
-    op = args.workload if args.workload in ("csum", "generate") else "verify"
+    op = args.workload if args.workload in ("csum", "generate", "txbuild") else "verify"
     batches = [Batch(ctx, stream, kind, ifc, r * n_global, n_global, shard_world, shard_rank, stride16, op) for r in range(rotate)]
     b0 = batches[0]
-    kernel = {"csum": "k_csum", "generate": "k_generate"}.get(op, "k_ipv4_validate" if kind == unet_amd.SYNTH_IPV4_HDR20 else "k_verify<MODE_L3>")
+    kernel = {"csum": "k_csum", "generate": "k_generate", "txbuild": "k_tx_build<MODE_L3>"}.get(op, "k_ipv4_validate" if kind == unet_amd.SYNTH_IPV4_HDR20 else "k_verify<MODE_L3>")
     torch.cuda.synchronize()
 
     # ---- timed region
@@ -315,6 +340,9 @@ def main():
     wall = shard.max_over_ranks(wall, "cuda", dist)
 
     # ---- epilogue: per-verdict counters, summed across GPUs (the only cross-GPU traffic)
+    if op == "txbuild":
+        # judge the built packets as the receiver would: every one must be accepted
+        ctx.verify_dev(b0.out_arena.data_ptr(), b0.out_bytes, None, 94, b0.olen.data_ptr(), b0.n, b0.rx, b0.out.data_ptr(), stream)
     if op == "csum":
         b0.out.zero_()  # 16-bit checksums are not verdicts: nothing to count
     d_cnt = b0.counts()
@@ -339,6 +367,9 @@ def main():
         local_cnt = d_cnt.cpu().numpy().copy()
         cnt = shard.allreduce_counts(d_cnt, dist).cpu().numpy()
         parity = bool(local_cnt[Verdict.ACCEPT_UDP] + local_cnt[Verdict.DROP_UDP_LEN] == b0.n)
+    if op == "txbuild":
+        parity = bool(local_cnt[Verdict.ACCEPT_UDP] == b0.n and int(b0.status.max().item()) == 0
+                      and int(b0.olen.min().item()) == 1500 == int(b0.olen.max().item()))
     if args.workload == "udp1500":
         # per-index fault rules of the trace: idx % 256 == 33 -> length mismatch; idx % 64 == 7 or
         # idx % 256 == 97 -> checksum failure (a zeroed field can verify only if the true value was 0)
@@ -359,6 +390,25 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     stream_gbps = b0.nbytes * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    copy_gbps = None
+    if op == "txbuild":
+        # read+write yardstick: a plain device-to-device copy of the payload arena into the packet arena
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        b0.out_arena[:b0.nbytes].copy_(b0.arena[:b0.nbytes])
+        e0.record()
+        for _ in range(5):
+            b0.out_arena[:b0.nbytes].copy_(b0.arena[:b0.nbytes])
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 2 * b0.nbytes * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ctx.stream_copy_dev(b0.arena.data_ptr(), b0.out_arena.data_ptr(), b0.nbytes, stream)
+        e0.record()
+        for _ in range(5):
+            ctx.stream_copy_dev(b0.arena.data_ptr(), b0.out_arena.data_ptr(), b0.nbytes, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbps = {"torch_copy": copy_gbps, "k_stream_copy": 2 * b0.nbytes * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9}
 
     if rank == 0:
         alg_bytes = sum(b.alg_bytes for b in batches) / rotate
@@ -400,7 +450,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": kernel,
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "stream_read_GBps": stream_gbps, "frac_of_stream_read": achieved / stream_gbps},
+                         "stream_read_GBps": stream_gbps, "frac_of_stream_read": achieved / stream_gbps,
+                         **({"d2d_copy_GBps": copy_gbps} if copy_gbps else {})},
             "hbm_GBps_all_gpus": sum(all_bytes) / rotate * args.steps / wall / 1e9,
             "verdict_counts": {Verdict(i).name: int(c) for i, c in enumerate(cnt) if c},
             "parity_check": parity,

@@ -283,6 +283,9 @@ uint32_t unet_synth_flow_hash(int kind, uint64_t seed, uint64_t idx, const unet_
  * one u32 per workgroup (at least 4096 slots). */
 int unet_stream_read_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t bytes,
                          uint32_t* d_sink);
+/* Read+write yardstick for the packet builder: copies bytes/16 16-byte chunks with streaming loads and
+ * stores.  No counterpart in the reference. */
+int unet_stream_copy_dev(unet_ctx* ctx, void* stream, const uint8_t* d_src, uint8_t* d_dst, uint64_t bytes);
 
 #ifdef __cplusplus
 }

@@ -159,6 +159,7 @@ _SIGS = {
     "unet_synth_shard_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(_IfaceC), C.c_uint32, _u8p]),
     "unet_synth_flow_hash": (C.c_uint32, [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(_IfaceC)]),
     "unet_stream_read_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p]),
+    "unet_stream_copy_dev": (C.c_int, [_vp, _vp, _u8p, _u8p, C.c_uint64]),
 }
 
 EXPORTS = tuple(_SIGS)
@@ -383,6 +384,9 @@ class Offload:
 
     def stream_read_dev(self, d_buf, nbytes, d_sink, stream=None):
         _check(self.lib.unet_stream_read_dev(self.h, stream, d_buf, nbytes, d_sink))
+
+    def stream_copy_dev(self, d_src, d_dst, nbytes, stream=None):
+        _check(self.lib.unet_stream_copy_dev(self.h, stream, d_src, d_dst, nbytes))
 
     # -- helpers --------------------------------------------------------------------------------
     @staticmethod

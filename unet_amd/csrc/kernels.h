@@ -464,11 +464,94 @@ __device__ __forceinline__ u32x4 splice(u32x4 lo, u32x4 hi) {
                  (hi.x >> 16) | (hi.y << 16)};
 }
 
+// Lane i receives lane i+1's value; lane 63 receives `after` (DPP wave_shl:1, unwritten lanes keep `old`).
+__device__ __forceinline__ u32 from_next_lane(u32 v, u32 after) {
+    return (u32)__builtin_amdgcn_update_dpp((int)after, (int)v, 0x130, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ void tx_store(u32x4 v, u32x4* p) {
+#ifdef UNET_TX_DEFAULT_STORE
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
+
+// Rows 0/1 of a payload, loaded SH lanes to the right: lane L holds payload chunk L - SH (row 0) and
+// L + 64 - SH (row 1), so that lane L ends up owning output chunk L (L + 64) of the packet.  Exactly two
+// unconditional, clamped load instructions, as in issue_rows.
+template <u32 SH>
+__device__ __forceinline__ Rows2 issue_rows_shifted(const Batch& b, u32 my_len, u32 my_slot, u32 lane, u32 j, bool live) {
+    Rows2 x;
+    x.j = j;
+    x.live = live;
+    x.flen = rdlane(my_len, j);
+    const u32 slot = rdlane(my_slot, j);
+    x.nch = live ? (x.flen + 15u) >> 4 : 0u;
+    x.p = reinterpret_cast<const u32x4*>(b.arena + (live ? (u64)slot * 16u : 0ull));
+    const u32 last = x.nch != 0u ? x.nch - 1u : 0u;
+    x.r0 = ld_row(x.p + min(lane < SH ? 0u : lane - SH, last));
+    x.r1 = ld_row(x.p + min(lane + kWave - SH, last));
+    return x;
+}
+
+// Builds one packet from the payload in `cur` and its prepared headers.  The packet is treated as one
+// byte stream, headers then payload, cut into the payload's 16-byte chunks: "virtual" chunk m holds stream
+// bytes [16m - R, 16m - R + 16), so chunks 0..SH-1 are the headers (parked in LDS by their lane, L4
+// checksum still blank) and chunk SH + k is payload chunk k.  Output chunk m = bytes R..15 of virtual
+// chunk m followed by bytes 0..R-1 of virtual chunk m + 1, which sits in the next lane's registers.
+// Returns nothing: rows 0/1 are stored last, whole, once the payload's sum has completed the L4 checksum
+// (the last 16-bit word of virtual chunk SH-1 for UDP, the third-last for ICMP).
+template <int R, u32 SH>
+__device__ __forceinline__ void tx_build_one(const Rows2& cur, u32 lane, u32 frame_len, u32x4* __restrict__ pout,
+                                             const u32x4* __restrict__ hdr, u32 l4_partial_be, bool udp) {
+    const u32 nin = cur.nch, nout = (frame_len + 15u) >> 4;
+    const TailMask tm(cur.flen, nin);
+    const u32 k0 = lane - SH, k1 = lane + kWave - SH;  // k0 wraps for the header lanes: they hold no payload
+    u32x4 a = tm.apply(zero_unless(cur.r0, lane >= SH && k0 < nin), k0);
+    const u32x4 c = tm.apply(zero_unless(cur.r1, k1 < nin), k1);
+    u32 acc = sum_chunk(c, sum_chunk(a, 0u));
+    // first dwords of the payload chunk after row 1, wanted by lane 63 of row 1
+    constexpr u32 kRows = 2u * kWave - SH;
+    u32 fx = 0, fy = 0;
+    if (nin > kRows) {
+        const u32x4 f = tm.apply(cur.p[kRows], kRows);
+        fx = f.x;
+        fy = f.y;
+    }
+    // payloads past rows 0/1: summed and stored straight from HBM
+    const u32 kend = max(nin, nout - SH);
+#pragma nounroll
+    for (u32 r = kRows; r < kend; r += kWave) {
+        const u32 k = r + lane;
+        u32x4 lo = {0, 0, 0, 0}, hi = lo;
+        if (k < nin) lo = tm.apply(ld_far(cur.p + k), k);
+        if (k + 1u < nin) hi = tm.apply(cur.p[k + 1u], k + 1u);
+        acc = sum_chunk(lo, acc);
+        if (k + SH < nout) tx_store(splice<R>(lo, hi), pout + k + SH);
+    }
+    const u32 pay_be = bswap16(fold16(wave_sum(acc)));  // payload's folded sum, big-endian domain
+    const u32 ck = bswap16((~fold16(l4_partial_be + pay_be)) & 0xffffu) << 16;
+    if (lane < SH) a = hdr[lane];
+    if (lane == SH - 1u) {
+        a.w |= udp ? ck : 0u;
+        a.z |= udp ? 0u : ck;
+    }
+    u32x4 ha = {0, 0, 0, 0}, hc = ha;
+    ha.x = from_next_lane(a.x, rdlane(c.x, 0));
+    hc.x = from_next_lane(c.x, fx);
+    if (R > 4) {
+        ha.y = from_next_lane(a.y, rdlane(c.y, 0));
+        hc.y = from_next_lane(c.y, fy);
+    }
+    if (lane < nout) tx_store(splice<R>(a, ha), pout + lane);
+    if (lane + kWave < nout) tx_store(splice<R>(c, hc), pout + lane + kWave);
+}
+
 // MODE_L3: packet = 28 header bytes + payload.  MODE_L2: 42 header bytes + payload (+ tap::send's pad).
-// Phase A, wave-cooperative per packet: the payload is read once in 16-byte chunks, summed, and stored
-// shifted by the header size (every output chunk splices two neighbouring input chunks).
-// Phase B, lane-parallel: lane j builds packet j's headers -- all checksums included -- and stores the
-// first 32 (48) bytes, which also hold the first 4 (6) payload bytes.
+// Lane j first prepares packet j's headers (every field and the IPv4 checksum; the L4 checksum as a
+// partial sum) and parks them in LDS; the wave then builds the packets one after another, reading each
+// payload once and writing each packet once, in whole 1 KiB rows from its first byte.
 template <int MODE, int TILE>
 __global__ __launch_bounds__(kBlock) void k_tx_build(Batch pay, const TxDesc* __restrict__ desc, IfaceDev ifc,
                                                      uint8_t* __restrict__ out_arena, u64 out_bytes,
@@ -478,6 +561,8 @@ __global__ __launch_bounds__(kBlock) void k_tx_build(Batch pay, const TxDesc* __
     constexpr u32 SH = MODE == MODE_L2 ? 3u : 2u;    // output chunks that contain header bytes
     constexpr int R = MODE == MODE_L2 ? 6 : 4;       // payload bytes inside the last header chunk
     static_assert(16u * SH - H == (u32)R, "header geometry");
+    __shared__ u32x4 lds[(kBlock / kWave) * TILE * SH];
+    u32x4* park = lds + (threadIdx.x >> 6) * (TILE * SH);
     Tile t;
     if (!t.init<TILE>(pay)) return;
     const u32 i = t.first + t.lane;
@@ -497,41 +582,25 @@ __global__ __launch_bounds__(kBlock) void k_tx_build(Batch pay, const TxDesc* __
     else if ((u64)my_oslot * 16u + (((u64)frame_len + 15u) & ~15ull) > out_bytes) st = UNET_TX_E_RANGE_;
     const bool my_go = t.lane < t.cnt && st == UNET_TX_OK_;
 
-    // ---- phase A
-    u32 my_total = 0;
     u64 todo = __ballot(my_go);
-    while (todo != 0ull) {
-        const u32 j = (u32)__builtin_ctzll(todo);
-        todo &= todo - 1ull;
-        const u32 plen = rdlane(t.my_len, j), flen = rdlane(frame_len, j);
-        const u32x4* pin = reinterpret_cast<const u32x4*>(pay.arena + (u64)rdlane(t.my_slot, j) * 16u);
-        u32x4* pout = reinterpret_cast<u32x4*>(out_arena + (u64)rdlane(my_oslot, j) * 16u);
-        const u32 nin = (plen + 15u) >> 4, nout = (flen + 15u) >> 4;
-        const TailMask tm(plen, nin);  // uniform masks for the payload's cut last chunk
-        const u32 kend = max(nin, nout - SH);
-        u32 acc = 0;
-        for (u32 k0 = 0; k0 < kend; k0 += kWave) {
-            const u32 k = k0 + t.lane;
-            u32x4 lo = {0, 0, 0, 0}, hi = lo;
-            if (k < nin) lo = tm.apply(ld_row(pin + k), k);
-            if (k + 1u < nin) hi = tm.apply(pin[k + 1u], k + 1u);
-            acc = sum_chunk(lo, acc);
-            if (k + SH < nout) __builtin_nontemporal_store(splice<R>(lo, hi), pout + k + SH);
-        }
-        const u32 total = wave_sum(acc);
-        if (t.lane == j) my_total = total;
+    Rows2 A, B, C;
+#define UNET_NEXT(X)                                                                 \
+    {                                                                                \
+        const bool has = todo != 0ull;                                               \
+        const u32 j = has ? (u32)__builtin_ctzll(todo) : 0u;                         \
+        todo &= todo - 1ull;                                                         \
+        X = issue_rows_shifted<SH>(pay, t.my_len, t.my_slot, t.lane, j, has);        \
+    }
+    const bool any = todo != 0ull;
+    if (any) {  // the first payloads are on their way while the headers are prepared
+        UNET_NEXT(A)
+        UNET_NEXT(B)
     }
 
-    // ---- phase B: headers as big-endian 16-bit words, checksums in that domain
+    // ---- headers as big-endian 16-bit words, checksums in that domain
+    u32 my_partial = 0;
+    const bool my_udp = proto == 17u;
     if (my_go) {
-        const u32x4* pin = reinterpret_cast<const u32x4*>(pay.arena + (u64)t.my_slot * 16u);
-        u32x4 in0 = {0, 0, 0, 0};
-        if (t.my_len != 0u) {
-            const LaneTail lt(t.my_len);
-            in0 = pin[0];
-            if (t.my_len < 16u) in0 = lt.apply(in0);
-        }
-        const u32 pay_be = bswap16(fold16(my_total));  // payload's folded sum, big-endian domain
         const u32 src = ifc.unicast, dst = d.dst;
         // create_ip_header, src/protocols/ipv4.rs:366-391
         const u32 ip[10] = {0x4500u, (20u + (8u + t.my_len)) & 0xffffu, d.id_proto & 0xffffu, 0u, (64u << 8) | proto, 0u,
@@ -541,24 +610,27 @@ __global__ __launch_bounds__(kBlock) void k_tx_build(Batch pay, const TxDesc* __
         for (int q = 0; q < 10; ++q) ipsum += ip[q];
         const u32 ipck = (~fold16(ipsum)) & 0xffffu;
         u32 l4[4];
-        if (proto == 17u) {
-            // udp::send, src/transport/udp.rs:181-203: pseudo-header uses the caller's src address
+        if (my_udp) {
+            // udp::send, src/transport/udp.rs:181-203: the pseudo-header uses the caller's src address
             const u32 length = (8u + t.my_len) & 0xffffu;
-            const u32 pseudo = (d.src >> 16) + (d.src & 0xffffu) + (dst >> 16) + (dst & 0xffffu) + 17u + length;
             l4[0] = d.l4ab & 0xffffu;
             l4[1] = d.l4ab >> 16;
             l4[2] = length;
-            l4[3] = (~fold16(pseudo + l4[0] + l4[1] + l4[2] + pay_be)) & 0xffffu;
+            l4[3] = 0u;
+            my_partial = (d.src >> 16) + (d.src & 0xffffu) + (dst >> 16) + (dst & 0xffffu) + 17u + length + l4[0] + l4[1] + l4[2];
         } else {
             // icmp::send, src/transport/icmp.rs:75-85
             l4[0] = d.l4ab & 0xffffu;  // type << 8 | code
+            l4[1] = 0u;
             l4[2] = d.values >> 16;
             l4[3] = d.values & 0xffffu;
-            l4[1] = (~fold16(l4[0] + l4[2] + l4[3] + pay_be)) & 0xffffu;
+            my_partial = l4[0] + l4[2] + l4[3];
         }
-        // little-endian halves of the wire bytes
-        u32 h[24];
+        // little-endian halves of the wire bytes, R bytes to the right (the virtual chunks of tx_build_one)
+        u32 h[8 * SH];
         int n = 0;
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q) h[n++] = 0u;
         if (MODE == MODE_L2) {
             h[n++] = d.mac_lo & 0xffffu;
             h[n++] = d.mac_lo >> 16;
@@ -572,20 +644,41 @@ __global__ __launch_bounds__(kBlock) void k_tx_build(Batch pay, const TxDesc* __
         for (int q = 0; q < 10; ++q) h[n++] = bswap16(q == 5 ? ipck : ip[q]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) h[n++] = bswap16(l4[q]);
-        h[n++] = in0.x & 0xffffu;
-        h[n++] = in0.x >> 16;
-        if (MODE == MODE_L2) h[n++] = in0.y & 0xffffu;
-        u32x4* pout = reinterpret_cast<u32x4*>(out_arena + (u64)my_oslot * 16u);
 #pragma unroll
         for (u32 c = 0; c < SH; ++c) {
-            pout[c] = u32x4{h[8 * c] | (h[8 * c + 1] << 16), h[8 * c + 2] | (h[8 * c + 3] << 16),
-                            h[8 * c + 4] | (h[8 * c + 5] << 16), h[8 * c + 6] | (h[8 * c + 7] << 16)};
+            park[t.lane * SH + c] = u32x4{h[8 * c] | (h[8 * c + 1] << 16), h[8 * c + 2] | (h[8 * c + 3] << 16),
+                                          h[8 * c + 4] | (h[8 * c + 5] << 16), h[8 * c + 6] | (h[8 * c + 7] << 16)};
         }
     }
     if (t.lane < t.cnt) {
         out_len[i] = st == UNET_TX_OK_ ? frame_len : 0u;
         if (status) status[i] = (uint8_t)st;
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the parked headers are read by lanes 0..SH-1
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- three register buffers in rotation, as in tile_sums: the loads of the next two payloads are
+    // in flight while one packet is assembled and stored
+#define UNET_CONSUME(X)                                                              \
+    tx_build_one<R, SH>(X, t.lane, rdlane(frame_len, X.j),                           \
+                        reinterpret_cast<u32x4*>(out_arena + (u64)rdlane(my_oslot, X.j) * 16u), park + X.j * SH, \
+                        rdlane(my_partial, X.j), rdlane((u32)my_udp, X.j) != 0u);
+    if (any) {
+#pragma nounroll
+        while (true) {
+            UNET_NEXT(C)
+            UNET_CONSUME(A)
+            if (!B.live) break;
+            UNET_NEXT(A)
+            UNET_CONSUME(B)
+            if (!C.live) break;
+            UNET_NEXT(B)
+            UNET_CONSUME(C)
+            if (!A.live) break;
+        }
+    }
+#undef UNET_NEXT
+#undef UNET_CONSUME
 }
 
 // ------------------------------------------------------------------ verdict histogram
@@ -681,6 +774,23 @@ __global__ __launch_bounds__(kBlock) void k_stream_read(const u32x4* __restrict_
     for (; i < hi; i += kBlock) acc = sum_chunk(ld_stream(buf + i), acc);
     acc = wave_sum(acc);
     if ((threadIdx.x & 63u) == 0u) atomicAdd(&sink[blockIdx.x & 4095u], acc);
+}
+
+// Read+write yardstick: plain copy with the same access pattern (slab per workgroup, 16 bytes per lane).
+__global__ __launch_bounds__(kBlock) void k_stream_copy(const u32x4* __restrict__ src, u32x4* __restrict__ dst, u64 nchunks) {
+    const u64 per = (nchunks + gridDim.x - 1) / gridDim.x;
+    const u64 lo = (u64)blockIdx.x * per;
+    const u64 hi = lo + per < nchunks ? lo + per : nchunks;
+    u64 i = lo + threadIdx.x;
+    for (; i + 3 * kBlock < hi; i += 4 * kBlock) {
+        const u32x4 a = ld_stream(src + i), b = ld_stream(src + i + kBlock), c = ld_stream(src + i + 2 * kBlock),
+                    d = ld_stream(src + i + 3 * kBlock);
+        __builtin_nontemporal_store(a, dst + i);
+        __builtin_nontemporal_store(b, dst + i + kBlock);
+        __builtin_nontemporal_store(c, dst + i + 2 * kBlock);
+        __builtin_nontemporal_store(d, dst + i + 3 * kBlock);
+    }
+    for (; i < hi; i += kBlock) __builtin_nontemporal_store(ld_stream(src + i), dst + i);
 }
 
 // ------------------------------------------------------------------ synthetic traces

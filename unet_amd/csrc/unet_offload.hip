@@ -621,4 +621,13 @@ int unet_stream_read_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint
     return UNET_OK;
 }
 
+int unet_stream_copy_dev(unet_ctx* ctx, void* stream, const uint8_t* d_src, uint8_t* d_dst, uint64_t bytes) {
+    if (!ctx || !d_src || !d_dst) return fail(UNET_E_INVAL, "null argument");
+    if ((((uintptr_t)d_src | (uintptr_t)d_dst) & 15u) != 0) return fail(UNET_E_INVAL, "buffers must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_stream_copy, dim3(4096), dim3(kBlock), 0, pick(ctx, stream), (const u32x4*)d_src, (u32x4*)d_dst, bytes / 16);
+    HIP_TRY(hipGetLastError());
+    return UNET_OK;
+}
+
 }  // extern "C"
