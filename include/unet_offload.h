@@ -283,6 +283,41 @@ uint32_t unet_synth_flow_hash(int kind, uint64_t seed, uint64_t idx, const unet_
  * one u32 per workgroup (at least 4096 slots). */
 int unet_stream_read_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t bytes,
                          uint32_t* d_sink);
+/* ------------------------------------------------ capture files <-> arenas (host code, no GPU involved) */
+/* What the reference's two devices hand to the stack: tap::read fills a 1514-byte buffer
+ * (src/driver/tap.rs:168-173, ETHERNET_FRAME_MAX_SIZE src/devices/ethernet.rs:10), so a longer frame arrives
+ * cut at 1514 bytes; the loopback device carries up to 65535 bytes (src/devices/loopback.rs:16). */
+#define UNET_TAP_FRAME_MAX 1514u
+#define UNET_LOOPBACK_MTU 65535u
+
+typedef struct unet_pcap_info {
+    uint32_t linktype;      /* 0 NULL, 1 EN10MB, 101 RAW, 228 IPV4 */
+    uint32_t snaplen;
+    uint32_t mode;          /* UNET_MODE_L2 for Ethernet captures, UNET_MODE_L3 for the others */
+    uint32_t skip;          /* link-layer bytes dropped in front of every record (4 for NULL) */
+    uint32_t n_records;     /* complete records in the file */
+    uint32_t n_snapped;     /* records the capture itself had cut (caplen < origlen) */
+    uint32_t n_clipped;     /* records cut to max_len by this import */
+    uint32_t nanosecond;    /* 1 if timestamps are in nanoseconds */
+    uint64_t arena_bytes;   /* size of the arena unet_pcap_pack needs (>= 16) */
+    uint64_t trailing_bytes;/* bytes after the last complete record */
+} unet_pcap_info;
+
+/* Classic pcap file (either byte order, micro- or nanosecond variant) held in memory -> counts and sizes.
+ * Records longer than max_len (UNET_TAP_FRAME_MAX, UNET_LOOPBACK_MTU, at most 65535) are cut to it. */
+int unet_pcap_scan(const uint8_t* file, uint64_t file_bytes, uint32_t max_len, unet_pcap_info* info);
+/* Packs the records into an arena (16-byte aligned, info.arena_bytes long; pad bytes are zeroed):
+ * record i at 16*off16[i], len[i] bytes; n must be info.n_records.  ts_ns (may be NULL) receives the
+ * timestamps in nanoseconds. */
+int unet_pcap_pack(const uint8_t* file, uint64_t file_bytes, uint32_t max_len, uint8_t* arena, uint64_t arena_bytes,
+                   uint32_t* off16, uint32_t* len, uint64_t* ts_ns, uint32_t n);
+/* Arena -> pcap (little-endian, microsecond timestamps i microseconds apart, snaplen 65535).  Returns the number
+ * of bytes the file needs in *file_bytes; writes it when `file` is non-NULL and file_cap is large enough.
+ * Records with len 0 (e.g. packets unet_tx_build_dev refused) are skipped. */
+int unet_pcap_write(const uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16, uint32_t stride16,
+                    const uint32_t* len, uint32_t n, uint32_t linktype, uint8_t* file, uint64_t file_cap,
+                    uint64_t* file_bytes);
+
 /* Read+write yardstick for the packet builder: copies bytes/16 16-byte chunks with streaming loads and
  * stores.  No counterpart in the reference. */
 int unet_stream_copy_dev(unet_ctx* ctx, void* stream, const uint8_t* d_src, uint8_t* d_dst, uint64_t bytes);

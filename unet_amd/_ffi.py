@@ -158,6 +158,9 @@ _SIGS = {
     "unet_synth_len_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_uint64, C.c_uint64, _u32p, C.c_uint32, _u32p]),
     "unet_synth_shard_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(_IfaceC), C.c_uint32, _u8p]),
     "unet_synth_flow_hash": (C.c_uint32, [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(_IfaceC)]),
+    "unet_pcap_scan": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp]),
+    "unet_pcap_pack": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _u8p, C.c_uint64, _u32p, _u32p, _u64p, C.c_uint32]),
+    "unet_pcap_write": (C.c_int, [_u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.c_uint32, _u8p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "unet_stream_read_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p]),
     "unet_stream_copy_dev": (C.c_int, [_vp, _vp, _u8p, _u8p, C.c_uint64]),
 }
@@ -249,6 +252,54 @@ def synth_flow_hash(kind: int, seed: int, idx: int, iface: Iface) -> int:
     """Flow hash of the 5-tuple that record `idx` of the trace carries (before fault injection)."""
     ic = iface.c()
     return int(load_library().unet_synth_flow_hash(kind, seed, idx, C.byref(ic)))
+
+
+TAP_FRAME_MAX = 1514      # src/driver/tap.rs:170
+LOOPBACK_MTU = 65535      # src/devices/loopback.rs:16
+LINKTYPE_NULL, LINKTYPE_ETHERNET, LINKTYPE_RAW, LINKTYPE_IPV4 = 0, 1, 101, 228
+
+
+class PcapInfo(C.Structure):
+    _fields_ = [("linktype", C.c_uint32), ("snaplen", C.c_uint32), ("mode", C.c_uint32), ("skip", C.c_uint32),
+                ("n_records", C.c_uint32), ("n_snapped", C.c_uint32), ("n_clipped", C.c_uint32), ("nanosecond", C.c_uint32),
+                ("arena_bytes", C.c_uint64), ("trailing_bytes", C.c_uint64)]
+
+
+def pcap_scan(data: bytes, max_len: int = LOOPBACK_MTU) -> PcapInfo:
+    info = PcapInfo()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    _check(load_library().unet_pcap_scan(_np_ptr(buf), len(data), max_len, C.addressof(info)))
+    return info
+
+
+def pcap_pack(data: bytes, max_len: int = LOOPBACK_MTU):
+    """Classic pcap file bytes -> (arena, off16, lens, ts_ns, info); records cut at max_len the way the device
+    would have delivered them (TAP_FRAME_MAX for tap0, LOOPBACK_MTU for lo)."""
+    info = pcap_scan(data, max_len)
+    buf = np.frombuffer(data, dtype=np.uint8)
+    n = info.n_records
+    arena = _aligned_u8(info.arena_bytes)
+    off16 = np.zeros(n, dtype=np.uint32)
+    lens = np.zeros(n, dtype=np.uint32)
+    ts = np.zeros(n, dtype=np.uint64)
+    _check(load_library().unet_pcap_pack(_np_ptr(buf), len(data), max_len, _np_ptr(arena), arena.nbytes, _np_ptr(off16),
+                                         _np_ptr(lens), _np_ptr(ts), n))
+    return arena, off16, lens, ts, info
+
+
+def pcap_write(arena: np.ndarray, off16, lens: np.ndarray, linktype: int = LINKTYPE_ETHERNET, stride16: int = 0) -> bytes:
+    arena = np.ascontiguousarray(arena, dtype=np.uint8)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    if off16 is not None:
+        off16 = np.ascontiguousarray(off16, dtype=np.uint32)
+    need = C.c_uint64(0)
+    lib = load_library()
+    _check(lib.unet_pcap_write(_np_ptr(arena), arena.nbytes, _np_ptr(off16), stride16, _np_ptr(lens), len(lens), linktype, None, 0,
+                               C.byref(need)))
+    out = np.zeros(need.value, dtype=np.uint8)
+    _check(lib.unet_pcap_write(_np_ptr(arena), arena.nbytes, _np_ptr(off16), stride16, _np_ptr(lens), len(lens), linktype,
+                               _np_ptr(out), out.nbytes, C.byref(need)))
+    return out.tobytes()
 
 
 def flow_hash5(src: int, dst: int, proto: int, sport: int, dport: int) -> int:

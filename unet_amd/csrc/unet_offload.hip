@@ -12,6 +12,7 @@
 #include <new>
 
 #include "kernels.h"
+#include "pcap.h"
 
 using namespace unetdev;
 
@@ -618,6 +619,93 @@ int unet_stream_read_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint
     HIP_TRY(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_stream_read, dim3(4096), dim3(kBlock), 0, pick(ctx, stream), (const u32x4*)d_buf, bytes / 16, d_sink);
     HIP_TRY(hipGetLastError());
+    return UNET_OK;
+}
+
+/* ---------------------------------------------------------------- capture files */
+int unet_pcap_scan(const uint8_t* file, uint64_t file_bytes, uint32_t max_len, unet_pcap_info* info) {
+    if (!file || !info) return fail(UNET_E_INVAL, "null argument");
+    if (max_len == 0 || max_len > 65535u) return fail(UNET_E_RANGE, "max_len %u outside 1..65535", max_len);
+    unetpcap::Header h;
+    if (const char* e = unetpcap::parse_header(file, file_bytes, &h)) return fail(UNET_E_INVAL, "%s", e);
+    std::memset(info, 0, sizeof(*info));
+    info->linktype = h.linktype;
+    info->snaplen = h.snaplen;
+    info->mode = (uint32_t)h.mode;
+    info->skip = h.skip;
+    info->nanosecond = h.nanos ? 1u : 0u;
+    uint64_t slots = 0;
+    uint32_t snapped = 0, clipped = 0;
+    info->n_records = unetpcap::for_each_record(file, file_bytes, h, max_len, &info->trailing_bytes,
+        [&](uint32_t, const uint8_t*, const uint8_t*, uint32_t kept, uint32_t caplen, uint32_t origlen) {
+            slots += (kept + 15u) >> 4;
+            snapped += caplen < origlen;
+            clipped += (caplen > h.skip ? caplen - h.skip : 0u) > kept;
+        });
+    info->n_snapped = snapped;
+    info->n_clipped = clipped;
+    info->arena_bytes = slots ? slots * 16u : 16u;
+    if (slots > 0xffffffffull) return fail(UNET_E_RANGE, "capture needs more than 2^32 16-byte slots");
+    return UNET_OK;
+}
+
+int unet_pcap_pack(const uint8_t* file, uint64_t file_bytes, uint32_t max_len, uint8_t* arena, uint64_t arena_bytes,
+                   uint32_t* off16, uint32_t* len, uint64_t* ts_ns, uint32_t n) {
+    if (!file || !arena || !off16 || !len) return fail(UNET_E_INVAL, "null argument");
+    if (((uintptr_t)arena & 15u) != 0) return fail(UNET_E_INVAL, "arena must be 16-byte aligned");
+    unet_pcap_info info;
+    int rc = unet_pcap_scan(file, file_bytes, max_len, &info);
+    if (rc) return rc;
+    if (n != info.n_records) return fail(UNET_E_INVAL, "n = %u but the capture holds %u records", n, info.n_records);
+    if (arena_bytes < info.arena_bytes) return fail(UNET_E_RANGE, "arena of %llu bytes, need %llu", (unsigned long long)arena_bytes,
+                                                    (unsigned long long)info.arena_bytes);
+    unetpcap::Header h;
+    unetpcap::parse_header(file, file_bytes, &h);
+    uint64_t slot = 0;
+    unetpcap::for_each_record(file, file_bytes, h, max_len, nullptr,
+        [&](uint32_t i, const uint8_t* rh, const uint8_t* data, uint32_t kept, uint32_t, uint32_t) {
+            const uint64_t padded = ((uint64_t)kept + 15u) & ~15ull;
+            uint8_t* dst = arena + slot * 16u;
+            std::memcpy(dst, data, kept);
+            std::memset(dst + kept, 0, padded - kept);
+            off16[i] = (uint32_t)slot;
+            len[i] = kept;
+            if (ts_ns) {
+                const uint64_t sec = unetpcap::rd32(rh, h.swapped), frac = unetpcap::rd32(rh + 4, h.swapped);
+                ts_ns[i] = sec * 1000000000ull + (h.nanos ? frac : frac * 1000ull);
+            }
+            slot += padded >> 4;
+        });
+    if (slot == 0) std::memset(arena, 0, 16);
+    return UNET_OK;
+}
+
+int unet_pcap_write(const uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16, uint32_t stride16,
+                    const uint32_t* len, uint32_t n, uint32_t linktype, uint8_t* file, uint64_t file_cap,
+                    uint64_t* file_bytes) {
+    if (!file_bytes || (n && (!arena || !len))) return fail(UNET_E_INVAL, "null argument");
+    if (n && !off16 && stride16 == 0) return fail(UNET_E_INVAL, "need off16 or a non-zero stride16");
+    uint64_t need = 24;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (len[i] > 65535u) return fail(UNET_E_RANGE, "record %u: length %u exceeds 65535", i, len[i]);
+        const uint64_t at = (off16 ? (uint64_t)off16[i] : (uint64_t)i * stride16) * 16u;
+        if (at + len[i] > arena_bytes) return fail(UNET_E_RANGE, "record %u lies outside the arena", i);
+        if (len[i]) need += 16u + len[i];
+    }
+    *file_bytes = need;
+    if (!file) return UNET_OK;
+    if (file_cap < need) return fail(UNET_E_RANGE, "file buffer of %llu bytes, need %llu", (unsigned long long)file_cap, (unsigned long long)need);
+    const uint32_t gh[6] = {unetpcap::kMagicUs, 2u | (4u << 16), 0u, 0u, 65535u, linktype};
+    std::memcpy(file, gh, 24);
+    uint8_t* p = file + 24;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!len[i]) continue;
+        const uint64_t at = (off16 ? (uint64_t)off16[i] : (uint64_t)i * stride16) * 16u;
+        const uint32_t rh[4] = {i / 1000000u, i % 1000000u, len[i], len[i]};
+        std::memcpy(p, rh, 16);
+        std::memcpy(p + 16, arena + at, len[i]);
+        p += 16u + len[i];
+    }
     return UNET_OK;
 }
 
