@@ -221,6 +221,17 @@ int unet_tx_build_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload_aren
                       const unet_tx_desc* d_desc, uint32_t n, const unet_iface* iface, uint8_t* d_out_arena,
                       uint64_t out_arena_bytes, const uint32_t* d_out_off16, uint32_t* d_out_len, uint8_t* d_status);
 
+/* Packed output layout for n payloads: out_off16[i] (may be NULL) and the arena size unet_tx_build needs.
+ * Host code. */
+int unet_tx_layout(const uint32_t* payload_len, uint32_t n, int mode, uint32_t* out_off16, uint64_t* out_arena_bytes);
+/* Host-pointer form: stages payloads and descriptors, builds on the GPU, copies the packets back packed
+ * back to back (layout as unet_tx_layout; out_off16 and out_len are written).  Slots of refused packets
+ * are zero-filled. */
+int unet_tx_build(unet_ctx* ctx, const uint8_t* payload_arena, uint64_t payload_arena_bytes, const uint32_t* payload_off16,
+                  uint32_t payload_stride16, const uint32_t* payload_len, const unet_tx_desc* desc, uint32_t n,
+                  const unet_iface* iface, uint8_t* out_arena, uint64_t out_arena_bytes, uint32_t* out_off16,
+                  uint32_t* out_len, uint8_t* status);
+
 /* ------------------------------------------------------------ counters */
 /* Histogram of verdicts: d_counts[v] += number of results with verdict v (UNET_V_COUNT
  * u64 slots, caller zeroes them).  The reference keeps no counters; these are what a

@@ -133,7 +133,8 @@ static void gpu_tests() {
         CHECK(sock->queue[0].data == pay && sock->queue[0].foreign.port == 5000 && sock->queue[0].foreign.address.v == me);
         CHECK(sock->queue[1].data.empty() && sock->queue[1].foreign.port == 77);
     }
-    // errors: no socket, bad checksum, protocol 6, broadcast echo cannot be answered
+    // errors: no socket, bad checksum, protocol 6, broadcast echo cannot be answered (the reply's source would
+    // be the broadcast address, which ipv4::send refuses: ipv4.rs:324-329)
     CHECK(rep.errors.size() == 4);
     bool saw_socket = false, saw_ck = false, saw_proto = false, saw_src = false;
     for (const std::string& e : rep.errors) {
@@ -155,10 +156,90 @@ static void gpu_tests() {
     }
 }
 
+// udp::send / icmp::send batches against oracle_tx_build, packet by packet; the reference's refusals.
+static void gpu_send_tests() {
+    Offload gpu(0);
+    Ipv4Interface tap(Ipv4Address{0xC0000202}, Ipv4Address{0xFFFFFF00});
+    tap.mac = {0x02, 0xaa, 0xbb, 0xcc, 0xdd, 0xee};
+    const MacAddress peer_mac = {0x02, 0x11, 0x22, 0x33, 0x44, 0x55};
+    const ArpResolver arp = [&](Ipv4Address a) -> std::optional<MacAddress> {
+        if (a.v == 0xC0000201) return peer_mac;
+        return std::nullopt;
+    };
+    std::vector<TxRequest> reqs;
+    auto udp = [&](uint32_t src, uint32_t dst, size_t n) {
+        TxRequest r;
+        r.proto = 17;
+        r.src = Endpoint{Ipv4Address{src}, 8000};
+        r.dst = Endpoint{Ipv4Address{dst}, 8001};
+        r.data.resize(n);
+        for (size_t i = 0; i < n; i++) r.data[i] = uint8_t(i * 31 + n);
+        return r;
+    };
+    reqs.push_back(udp(0xC0000202, 0xC0000201, 20));     // 0 ok
+    reqs.push_back(udp(0, 0xC0000201, 1400));            // 1 ok, ANY source (pseudo-header uses 0.0.0.0)
+    reqs.push_back(udp(0, 0xFFFFFFFF, 10));              // 2 "source address is required for broadcast packet"
+    reqs.push_back(udp(0xC0000203, 0xC0000201, 10));     // 3 "unable to send packet with the source address"
+    reqs.push_back(udp(0xC0000202, 0xC0000201, 1492));   // 4 "packet too long" (8 + 1492 is not < 1500)
+    reqs.push_back(udp(0xC0000202, 0xC0000201, 70000));  // 5 "udp packet too long"
+    reqs.push_back(udp(0xC0000202, 0xC00002FF, 0));      // 6 ok, subnet broadcast, empty datagram
+    reqs.push_back(udp(0xC0000202, 0xC0000207, 33));     // 7 L2: no ARP entry -> unresolved; L3: ok
+    {
+        TxRequest r;
+        r.proto = 1;
+        r.src.address.v = 0xC0000202;
+        r.dst.address.v = 0xC0000201;
+        r.icmp_type = 8;
+        r.icmp_code = 0;
+        r.icmp_values = 0x00800001;
+        r.data.assign(56, 0x5a);
+        reqs.push_back(r);                               // 8 ok, echo request
+    }
+    for (int l2 = 0; l2 < 2; l2++) {
+        Ipv4IdGenerator ids;
+        ids.id = 128;
+        const TxReport rep = send_batch(gpu, tap, ids, reqs, l2 != 0, arp);
+        const std::vector<int> ok = l2 ? std::vector<int>{0, 1, 6, 8} : std::vector<int>{0, 1, 6, 7, 8};
+        CHECK(rep.packets.size() == ok.size());
+        CHECK(rep.errors.size() == 4 && rep.unresolved == (l2 ? 1u : 0u));
+        CHECK(ids.id == 128 + 5);  // the unresolved packet consumed an id as well
+        const unet_iface ci = tap.c_iface(l2 != 0);
+        oracle_iface oi{};
+        std::memcpy(&oi, &ci, sizeof oi);
+        const int id_of[9] = {128, 129, -1, -1, -1, -1, 130, 131, 132};
+        for (size_t k = 0; k < ok.size() && k < rep.packets.size(); k++) {
+            const TxRequest& r = reqs[ok[k]];
+            oracle_tx_desc d{};
+            d.src = r.src.address.v;
+            d.dst = r.dst.address.v;
+            d.proto = r.proto;
+            d.ip_id = uint16_t(id_of[ok[k]]);
+            if (r.proto == 17) { d.l4a = r.src.port; d.l4b = r.dst.port; }
+            else { d.l4a = uint16_t((r.icmp_type << 8) | r.icmp_code); d.values = r.icmp_values; }
+            if (l2) std::memcpy(d.dst_mac, r.dst.address.v == 0xC00002FF ? MacAddress{0xff, 0xff, 0xff, 0xff, 0xff, 0xff}.data() : peer_mac.data(), 6);
+            std::vector<uint8_t> want(14 + 20 + 8 + r.data.size() + 64);
+            uint8_t st = 0;
+            want.resize(oracle_tx_build(&d, r.data.data(), r.data.size(), &oi, want.data(), &st));
+            CHECK(st == 0 && rep.packets[k].bytes == want && rep.packets[k].dst.v == r.dst.address.v);
+        }
+        bool e0 = false, e1 = false, e2 = false, e3 = false;
+        for (const std::string& e : rep.errors) {
+            e0 |= e == "source address is required for broadcast packet";
+            e1 |= e == "unable to send packet with the source address, src: 192.0.2.3, interface: 192.0.2.2";
+            e2 |= e == "packet too long, len: 1500, mtu: 1500";
+            e3 |= e == "udp packet too long, len: 70000, max: 65507";
+        }
+        CHECK(e0 && e1 && e2 && e3);
+    }
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "--cpu";
     cpu_tests();
-    if (mode == "--gpu") gpu_tests();
+    if (mode == "--gpu") {
+        gpu_tests();
+        gpu_send_tests();
+    }
     if (g_fail) {
         std::printf("%d check(s) failed\n", g_fail);
         return 1;

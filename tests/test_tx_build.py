@@ -236,3 +236,22 @@ def test_tx_build_too_long_and_config1_reply(offload):
     assert got_len.tolist() == [98] and got[:98].tobytes() == exp[:98].tobytes()
     peer = unet_amd.Iface("192.0.2.1", "255.255.255.0", mac=peer_mac, mode=unet_amd.MODE_L2)
     assert O.recv(got[:98].tobytes(), peer)[0] == Verdict.ACCEPT_ICMP_ECHOREPLY
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [unet_amd.MODE_L3, unet_amd.MODE_L2])
+def test_tx_build_host_pointer_entry(offload, mode):
+    rng = np.random.default_rng(23)
+    ifc = unet_amd.Iface("192.0.2.2", "255.255.255.0", mac=bytes.fromhex("02aabbccddee"), mode=mode)
+    lens = LENS + [int(x) for x in rng.integers(0, 3000, size=800)]
+    desc, payloads = make_batch(rng, lens, ifc)
+    desc["proto"][5] = 99
+    arena, off16, plen = unet_amd.pack_arena(payloads)
+    got, got_off, got_len, got_status = offload.tx_build(arena, off16, plen, desc, ifc)
+    ooff, obytes = tx_out_layout(plen, mode)
+    assert (got_off == ooff).all() and got.nbytes == obytes
+    exp, exp_len, exp_status = O.tx_build_batch(arena, off16, plen, desc, ifc, ooff, obytes)
+    assert (got_status == exp_status).all() and got_status[5] == TX_E_PROTO and (got_len == exp_len).all()
+    m = _valid_mask(obytes, ooff, exp_len)
+    assert (got[m] == exp[m]).all() and (got[~m] == 0).all()
+    assert offload.tx_build(arena[:16], off16[:0], plen[:0], desc[:0], ifc)[2].size == 0

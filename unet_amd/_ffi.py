@@ -147,6 +147,9 @@ _SIGS = {
     "unet_generate": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, _u8p]),
     "unet_tx_build_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, _vp, C.c_uint32, C.POINTER(_IfaceC), _u8p,
                                     C.c_uint64, _u32p, _u32p, _u8p]),
+    "unet_tx_layout": (C.c_int, [_u32p, C.c_uint32, C.c_int, _u32p, C.POINTER(C.c_uint64)]),
+    "unet_tx_build": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, _vp, C.c_uint32, C.POINTER(_IfaceC), _u8p, C.c_uint64,
+                                _u32p, _u32p, _u8p]),
     "unet_count_verdicts_dev": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _u64p]),
     "unet_flow_hash5": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint16, C.c_uint16]),
     "unet_flow_hash_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _u32p]),
@@ -389,6 +392,25 @@ class Offload:
         _check(self.lib.unet_generate(self.h, _np_ptr(arena), arena.nbytes, _np_ptr(off16), stride16, _np_ptr(lens), n,
                                       _np_ptr(status)))
         return arena, status
+
+    def tx_build(self, payload_arena: np.ndarray, payload_off16, payload_lens: np.ndarray, desc: np.ndarray, iface: Iface,
+                 payload_stride16: int = 0):
+        """Returns (packet arena, out_off16, out_len, status)."""
+        arena, off16, lens = self._prep(payload_arena, payload_off16, payload_lens)
+        desc = np.ascontiguousarray(desc)
+        assert desc.dtype.itemsize == 28 and len(desc) == len(lens)
+        n = len(lens)
+        need = C.c_uint64(0)
+        _check(self.lib.unet_tx_layout(_np_ptr(lens), n, int(iface.mode), None, C.byref(need)))
+        out = _aligned_u8(need.value)
+        out_off = np.zeros(n, dtype=np.uint32)
+        out_len = np.zeros(n, dtype=np.uint32)
+        status = np.zeros(n, dtype=np.uint8)
+        ic = iface.c()
+        _check(self.lib.unet_tx_build(self.h, _np_ptr(arena), arena.nbytes, _np_ptr(off16), payload_stride16, _np_ptr(lens),
+                                      desc.ctypes.data, n, C.byref(ic), _np_ptr(out), out.nbytes, _np_ptr(out_off), _np_ptr(out_len),
+                                      _np_ptr(status)))
+        return out, out_off, out_len, status
 
     # -- device-pointer entry points ----------------------------------------------------------
     def csum_batch_dev(self, d_arena, arena_bytes, d_off16, stride16, d_len, d_seeds, n, d_out, stream=None):

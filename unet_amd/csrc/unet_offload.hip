@@ -56,7 +56,7 @@ struct unet_ctx {
     void* pinned[2] = {nullptr, nullptr};
     hipEvent_t pinned_free[2] = {nullptr, nullptr};
     hipEvent_t copied = nullptr;
-    DevBuf d_arena, d_off, d_len, d_out, d_aux;
+    DevBuf d_arena, d_off, d_len, d_out, d_aux, d_tx, d_tx_tab;
 };
 
 namespace {
@@ -211,7 +211,7 @@ void unet_close(unet_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->s_comp) (void)hipStreamSynchronize(c->s_comp);
     if (c->s_copy) (void)hipStreamSynchronize(c->s_copy);
-    DevBuf* bufs[] = {&c->d_arena, &c->d_off, &c->d_len, &c->d_out, &c->d_aux};
+    DevBuf* bufs[] = {&c->d_arena, &c->d_off, &c->d_len, &c->d_out, &c->d_aux, &c->d_tx, &c->d_tx_tab};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < 2; i++) {
@@ -444,6 +444,55 @@ int unet_tx_build_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload_aren
                            ifc, d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status);
     HIP_TRY(hipGetLastError());
     return UNET_OK;
+}
+
+int unet_tx_layout(const uint32_t* payload_len, uint32_t n, int mode, uint32_t* out_off16, uint64_t* out_arena_bytes) {
+    if ((n && !payload_len) || !out_arena_bytes) return fail(UNET_E_INVAL, "null argument");
+    if (mode != UNET_MODE_L3 && mode != UNET_MODE_L2) return fail(UNET_E_INVAL, "bad mode %d", mode);
+    u64 slot = 0;
+    for (u32 i = 0; i < n; i++) {
+        if (payload_len[i] > kMaxLen) return fail(UNET_E_RANGE, "payload %u: length %u > 65535", i, payload_len[i]);
+        const u64 l3 = 28ull + payload_len[i];
+        const u64 frame = mode == UNET_MODE_L2 ? 14ull + (l3 < 60 ? 60 : l3) : l3;
+        if (slot > 0xffffffffull) return fail(UNET_E_RANGE, "output needs more than 2^32 16-byte slots");
+        if (out_off16) out_off16[i] = (u32)slot;
+        slot += (frame + 15u) >> 4;
+    }
+    *out_arena_bytes = slot ? slot * 16u : 16u;
+    return UNET_OK;
+}
+
+int unet_tx_build(unet_ctx* c, const uint8_t* payload_arena, uint64_t payload_arena_bytes, const uint32_t* payload_off16,
+                  uint32_t payload_stride16, const uint32_t* payload_len, const unet_tx_desc* desc, uint32_t n,
+                  const unet_iface* iface, uint8_t* out_arena, uint64_t out_arena_bytes, uint32_t* out_off16,
+                  uint32_t* out_len, uint8_t* status) {
+    if (!c) return fail(UNET_E_INVAL, "null context");
+    if (n == 0) return UNET_OK;
+    if (!payload_arena || !payload_len || !desc || !iface || !out_arena || !out_off16 || !out_len) return fail(UNET_E_INVAL, "null argument");
+    if (!payload_off16 && payload_stride16 == 0) return fail(UNET_E_INVAL, "need an offset table or a non-zero stride");
+    u64 need = 0;
+    int rc = unet_tx_layout(payload_len, n, iface->mode, out_off16, &need);
+    if (rc) return rc;
+    if (out_arena_bytes < need) return fail(UNET_E_RANGE, "output arena of %llu bytes, need %llu", (unsigned long long)out_arena_bytes, (unsigned long long)need);
+    HIP_TRY(hipSetDevice(c->device));
+    Batch b;
+    if ((rc = upload_batch(c, payload_arena, payload_arena_bytes, payload_off16, payload_stride16, payload_len, n, &b))) return rc;
+    // tables: descriptors | output offsets | output lengths | status
+    const size_t o_desc = 0, o_off = (size_t)n * sizeof(unet_tx_desc), o_len = o_off + (size_t)n * 4, o_st = o_len + (size_t)n * 4;
+    if ((rc = ensure(c, c->d_tx_tab, o_st + n))) return rc;
+    if ((rc = ensure(c, c->d_tx, need))) return rc;
+    char* tab = (char*)c->d_tx_tab.p;
+    if ((rc = h2d(c, tab + o_desc, desc, (size_t)n * sizeof(unet_tx_desc)))) return rc;
+    if ((rc = h2d(c, tab + o_off, out_off16, (size_t)n * 4))) return rc;
+    if ((rc = copies_before_compute(c))) return rc;
+    // refused packets leave their slots untouched: start from zeros so the caller's copy is defined
+    HIP_TRY(hipMemsetAsync(c->d_tx.p, 0, need, c->s_comp));
+    rc = unet_tx_build_dev(c, nullptr, b.arena, b.arena_bytes, b.off16, b.stride16, b.len, (const unet_tx_desc*)(tab + o_desc), n, iface,
+                           (uint8_t*)c->d_tx.p, need, (const uint32_t*)(tab + o_off), (uint32_t*)(tab + o_len), (uint8_t*)(tab + o_st));
+    if (rc) return rc;
+    if ((rc = d2h_sync(c, out_len, tab + o_len, (size_t)n * 4))) return rc;
+    if (status && (rc = d2h_sync(c, status, tab + o_st, (size_t)n))) return rc;
+    return d2h_sync(c, out_arena, c->d_tx.p, need);
 }
 
 /* ---------------------------------------------------------------- counters */

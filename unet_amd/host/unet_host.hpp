@@ -8,8 +8,10 @@
 //     icmp::recv / send      src/transport/icmp.rs:66-122   (echo -> echo reply)
 // Here the queue is drained into one arena, ONE unet_verify call decides every packet on the GPU, and
 // this file performs what the reference does after its checks have passed: UDP PCB lookup / enqueue
-// (udp.rs:256-277) and echo-reply construction (icmp.rs:110-120, ipv4.rs:337-339,366-391).  The replies'
-// IPv4 and ICMP checksums are filled by ONE unet_generate call: no checksum is computed on the host.
+// (udp.rs:256-277) and the echo replies (icmp.rs:110-120).  Transmission is batched the same way:
+// udp::send / icmp::send requests (udp.rs:168-216, icmp.rs:66-95) pass ipv4::send's host-side checks
+// (ipv4.rs:320-335) here and are then built -- headers, checksums, Ethernet framing -- by ONE
+// unet_tx_build call: no checksum is computed and no header is serialised on the host.
 //
 // Header-only, C++17, needs only include/unet_offload.h and the shared library.
 #pragma once
@@ -18,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <optional>
 #include <stdexcept>
@@ -147,6 +150,31 @@ class Offload {
         return status;
     }
 
+    // Packets built from payloads + descriptors (unet_tx_build); returned packed, one vector per packet
+    // (empty for a refused one).
+    std::vector<std::vector<uint8_t>> tx_build(FrameArena& payloads, const std::vector<unet_tx_desc>& desc, const unet_iface& iface,
+                                               std::vector<uint8_t>* status_out = nullptr) const {
+        const uint32_t n = static_cast<uint32_t>(payloads.size());
+        std::vector<std::vector<uint8_t>> out(n);
+        if (n == 0) return out;
+        if (desc.size() != n) throw std::invalid_argument("one descriptor per payload");
+        uint64_t need = 0;
+        if (unet_tx_layout(payloads.len(), n, iface.mode, nullptr, &need) != UNET_OK)
+            throw std::runtime_error(std::string("unet_tx_layout: ") + unet_last_error());
+        void* raw = nullptr;
+        if (posix_memalign(&raw, 64, need) != 0) throw std::bad_alloc();
+        std::unique_ptr<uint8_t, decltype(&std::free)> arena(static_cast<uint8_t*>(raw), &std::free);
+        std::vector<uint32_t> off(n), len(n);
+        std::vector<uint8_t> status(n);
+        if (unet_tx_build(ctx_, payloads.data(), payloads.bytes(), payloads.off16(), 0, payloads.len(), desc.data(), n, &iface, arena.get(),
+                          need, off.data(), len.data(), status.data()) != UNET_OK)
+            throw std::runtime_error(std::string("unet_tx_build: ") + unet_last_error());
+        for (uint32_t i = 0; i < n; i++)
+            if (status[i] == UNET_TX_OK) out[i].assign(arena.get() + size_t(off[i]) * 16, arena.get() + size_t(off[i]) * 16 + len[i]);
+        if (status_out) *status_out = std::move(status);
+        return out;
+    }
+
   private:
     unet_ctx* ctx_ = nullptr;
 };
@@ -204,11 +232,121 @@ struct Ipv4QueueEntry {  // src/protocols.rs:52-57
     std::shared_ptr<Ipv4Interface> interface;
 };
 
-// An L3 packet the stack wants to transmit (what ipv4::send hands to the device layer after routing).
+// A finished packet: what ipv4::send hands to the device (L3 bytes), or in L2 mode the frame tap::send
+// writes to the TAP file.
 struct TxPacket {
     Ipv4Address dst;
     std::vector<uint8_t> bytes;
 };
+
+// The arguments of one udp::send (udp.rs:168-173) or icmp::send (icmp.rs:66-74) call.
+struct TxRequest {
+    uint8_t proto = 17;   // 17: udp::send, 1: icmp::send
+    Endpoint src, dst;    // ports are unused for ICMP
+    uint8_t icmp_type = 0, icmp_code = 0;
+    uint32_t icmp_values = 0;
+    std::vector<uint8_t> data;
+};
+
+struct TxReport {
+    std::vector<TxPacket> packets;    // in request order, refused and unresolved requests left out
+    std::vector<std::string> errors;  // the reference's anyhow messages
+    size_t unresolved = 0;            // L2 mode: next hop not in the ARP cache (ipv4.rs:352-357 returns Ok)
+};
+
+using MacAddress = std::array<uint8_t, 6>;
+using ArpResolver = std::function<std::optional<MacAddress>(Ipv4Address)>;  // the Resolved state of the ARP cache
+
+// Collects send requests that passed the host-side checks, then builds them all in one offload call.
+class TxBatch {
+  public:
+    // udp::send's length check (udp.rs:174-180) and ipv4::send's checks (ipv4.rs:320-335); takes the next
+    // identification only for a packet that will be built (ipv4.rs:337).  Returns false and reports why
+    // when the reference would have bailed out.
+    bool add(const TxRequest& r, const Ipv4Interface& ifc, Ipv4IdGenerator& ids, bool l2, const ArpResolver& arp, TxReport& rep) {
+        constexpr size_t kIpv4PayloadMax = 65535 - 20;  // ipv4.rs:18-20
+        if (r.proto == 17 && r.data.size() > kIpv4PayloadMax - 8) {
+            rep.errors.push_back("udp packet too long, len: " + std::to_string(r.data.size()) + ", max: " + std::to_string(kIpv4PayloadMax - 8));
+            return false;
+        }
+        const Ipv4Address src = r.src.address, dst = r.dst.address;
+        if (!(src.v != Ipv4Address::ANY || dst.v != Ipv4Address::BROADCAST)) {
+            rep.errors.push_back("source address is required for broadcast packet");
+            return false;
+        }
+        if (!(src.v == Ipv4Address::ANY || src == ifc.unicast)) {
+            rep.errors.push_back("unable to send packet with the source address, src: " + src.to_string() + ", interface: " + ifc.unicast.to_string());
+            return false;
+        }
+        const size_t l4len = 8 + r.data.size();
+        if (!(l4len < ifc.mtu)) {
+            rep.errors.push_back("packet too long, len: " + std::to_string(l4len) + ", mtu: " + std::to_string(ifc.mtu));
+            return false;
+        }
+        unet_tx_desc d{};
+        d.src = src.v;
+        d.dst = dst.v;
+        d.proto = r.proto;
+        if (r.proto == 17) {
+            d.l4a = r.src.port;
+            d.l4b = r.dst.port;
+        } else {
+            d.l4a = uint16_t((r.icmp_type << 8) | r.icmp_code);
+            d.values = r.icmp_values;
+        }
+        if (l2) {  // ipv4.rs:341-362
+            if (dst == ifc.broadcast || dst.v == Ipv4Address::BROADCAST) {
+                std::memset(d.dst_mac, 0xff, 6);
+            } else {
+                const std::optional<MacAddress> mac = arp ? arp(dst) : std::nullopt;
+                d.ip_id = ids.next();  // the reference has built the packet before it consults the ARP cache
+                if (!mac) {
+                    rep.unresolved++;
+                    return false;
+                }
+                std::memcpy(d.dst_mac, mac->data(), 6);
+                payloads_.push(r.data.data(), r.data.size());
+                desc_.push_back(d);
+                dst_.push_back(dst);
+                return true;
+            }
+        }
+        d.ip_id = ids.next();
+        payloads_.push(r.data.data(), r.data.size());
+        desc_.push_back(d);
+        dst_.push_back(dst);
+        return true;
+    }
+    size_t size() const { return desc_.size(); }
+    void flush(const Offload& gpu, const Ipv4Interface& ifc, bool l2, TxReport& rep) {
+        if (desc_.empty()) return;
+        const unet_iface ci = ifc.c_iface(l2);
+        std::vector<uint8_t> status;
+        std::vector<std::vector<uint8_t>> built = gpu.tx_build(payloads_, desc_, ci, &status);
+        for (size_t i = 0; i < built.size(); i++) {
+            if (status[i] != UNET_TX_OK) { rep.errors.push_back("packet not built, status " + std::to_string(status[i])); continue; }
+            rep.packets.push_back(TxPacket{dst_[i], std::move(built[i])});
+        }
+        payloads_.clear();
+        desc_.clear();
+        dst_.clear();
+    }
+
+  private:
+    FrameArena payloads_;
+    std::vector<unet_tx_desc> desc_;
+    std::vector<Ipv4Address> dst_;
+};
+
+// Batched udp::send / icmp::send over one interface: host checks per request, one build call for all.
+inline TxReport send_batch(const Offload& gpu, const Ipv4Interface& ifc, Ipv4IdGenerator& ids, const std::vector<TxRequest>& requests,
+                           bool l2 = false, const ArpResolver& arp = nullptr) {
+    TxReport rep;
+    TxBatch batch;
+    for (const TxRequest& r : requests) batch.add(r, ifc, ids, l2, arp, rep);
+    batch.flush(gpu, ifc, l2, rep);
+    return rep;
+}
 
 struct RecvReport {
     std::vector<unet_result> results;  // one per drained entry, in queue order
@@ -236,8 +374,6 @@ class NetProtocol {
         queue.clear();
         rep.results.resize(entries.size());
         std::vector<char> done(entries.size(), 0);
-        FrameArena tx;
-        std::vector<Ipv4Address> tx_dst;
         for (size_t first = 0; first < entries.size(); first++) {
             if (done[first]) continue;
             // one arena + one launch per distinct interface, queue order kept inside it
@@ -252,17 +388,15 @@ class NetProtocol {
                 }
             const unet_iface ci = ifp->c_iface(false, ext_tcp);
             const std::vector<unet_result> res = gpu.verify(arena_, ci);
+            TxBatch tx;
+            TxReport txr;
             for (size_t k = 0; k < idx.size(); k++) {
                 rep.results[idx[k]] = res[k];
-                follow_up(entries[idx[k]], res[k], *ifp, pcbs, ids, rep, tx, tx_dst);
+                follow_up(entries[idx[k]], res[k], *ifp, pcbs, ids, rep, tx, txr);
             }
-        }
-        if (tx.size()) {
-            const std::vector<uint8_t> st = gpu.generate(tx);  // IPv4 + ICMP checksums of every reply
-            for (size_t i = 0; i < tx.size(); i++) {
-                if (st[i] != 0) { rep.errors.push_back("reply not filled, status " + std::to_string(st[i])); continue; }
-                rep.replies.push_back(TxPacket{tx_dst[i], std::vector<uint8_t>(tx.record(i), tx.record(i) + tx.record_len(i))});
-            }
+            tx.flush(gpu, *ifp, false, txr);  // every echo reply of this interface: one build call
+            for (TxPacket& p : txr.packets) rep.replies.push_back(std::move(p));
+            for (std::string& e : txr.errors) rep.errors.push_back(std::move(e));
         }
         return rep;
     }
@@ -271,7 +405,7 @@ class NetProtocol {
     FrameArena arena_;
 
     static void follow_up(const Ipv4QueueEntry& e, const unet_result& r, const Ipv4Interface& ifc, UdpContext& pcbs,
-                          Ipv4IdGenerator& ids, RecvReport& rep, FrameArena& tx, std::vector<Ipv4Address>& tx_dst) {
+                          Ipv4IdGenerator& ids, RecvReport& rep, TxBatch& tx, TxReport& txr) {
         const uint8_t* d = e.data.data();
         switch (r.verdict) {
             case UNET_V_ACCEPT_UDP: {  // udp.rs:256-277
@@ -288,39 +422,18 @@ class NetProtocol {
                 rep.udp_enqueued++;
                 break;
             }
-            case UNET_V_ACCEPT_ICMP_ECHO: {  // icmp.rs:110-120 -> icmp::send -> ipv4::send
+            case UNET_V_ACCEPT_ICMP_ECHO: {  // icmp.rs:110-120: send(EchoReply, code, values, &data[8..], dst, src)
                 const size_t hl = size_t(d[0] & 0x0f) * 4;
-                const Ipv4Address req_src{be32(d + 12)}, req_dst{be32(d + 16)};
                 const uint8_t* msg = d + hl;
-                const size_t mlen = e.data.size() - hl;
-                // ipv4::send refuses a source that is not the interface address (ipv4.rs:324-329) ...
-                if (req_dst.v != Ipv4Address::ANY && req_dst != ifc.unicast) {
-                    rep.errors.push_back("unable to send packet with the source address, src: " + req_dst.to_string() +
-                                         ", interface: " + ifc.unicast.to_string());
-                    break;
-                }
-                // ... and a packet that does not fit the device (strict `<`, ipv4.rs:330-335)
-                if (!(mlen < ifc.mtu)) {
-                    rep.errors.push_back("packet too long, len: " + std::to_string(mlen) + ", mtu: " + std::to_string(ifc.mtu));
-                    break;
-                }
-                std::vector<uint8_t> p(20 + mlen);
-                // create_ip_header, ipv4.rs:366-391 (checksum field left 0: filled on the GPU)
-                p[0] = 0x45;
-                p[1] = 0;
-                put16(&p[2], uint16_t(20 + mlen));
-                put16(&p[4], ids.next());
-                put16(&p[6], 0);
-                p[8] = 64;
-                p[9] = 1;
-                put32(&p[12], ifc.unicast.v);
-                put32(&p[16], req_src.v);
-                // IcmpHeader{EchoReply, code, checksum 0, values} + data[8..], icmp.rs:75-82
-                p[20] = 0;
-                p[21] = msg[1];
-                std::memcpy(&p[24], msg + 4, mlen - 4);
-                tx.push(p.data(), p.size());
-                tx_dst.push_back(req_src);
+                TxRequest q;
+                q.proto = 1;
+                q.src.address.v = be32(d + 16);
+                q.dst.address.v = be32(d + 12);
+                q.icmp_type = 0;
+                q.icmp_code = msg[1];
+                q.icmp_values = be32(msg + 4);
+                q.data.assign(msg + 8, d + e.data.size());
+                tx.add(q, ifc, ids, false, nullptr, txr);
                 break;
             }
             case UNET_V_ACCEPT_ICMP_ECHOREPLY:
