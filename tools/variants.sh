@@ -7,5 +7,5 @@ for lib in unet_amd/lib/libunet_offload.so unet_amd/lib/variants/*.so; do
   [ -f "$lib" ] || continue
   echo "== $lib"
   UNET_OFFLOAD_LIB=$PWD/$lib timeout -k 10 120 python bench.py --workload $w --steps 20 --cpu-seconds 0 "$@" 2>/dev/null \
-    | python -c 'import sys,json; d=json.loads(sys.stdin.read()); r=d["roofline"]; print("%.1f GB/s  %.3f ms  parity=%s copy=%s" % (r["achieved"], r["kernel_ms"], d["parity_check"], r.get("d2d_copy_GBps")))' || exit 1
+    | python -c 'import sys,json; d=json.loads(sys.stdin.read()); r=d["roofline"]; print("%.1f GB/s  %.3f ms  parity=%s copy=%s" % (r["achieved"], r["kernel_ms"], d.get("parity_check"), r.get("d2d_copy_GBps")))' || exit 1
 done

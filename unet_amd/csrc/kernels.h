@@ -87,19 +87,27 @@ struct Tile {
     }
 };
 
-// Rows 0 and 1 (the first 2 KiB) of one record, as loaded by a whole wave.
+// Up to 2 KiB of one record, as loaded by a whole wave: `tail` always holds the record's end (or its
+// chunks 64..127 when the record goes on past 2 KiB), `head` holds chunks 0..63 of a record longer than
+// 1 KiB and is a dummy otherwise.
 struct Rows2 {
-    u32x4 r0, r1;
+    u32x4 head, tail;
     const u32x4* p;
     u32 flen, nch, j;
     bool live;
+    __device__ __forceinline__ bool two() const { return nch > kWave; }           // head is in use
+    __device__ __forceinline__ u32 tail_base() const { return two() ? kWave : 0u; }  // chunk index of tail's lane 0
 };
 
 // Issue (not wait for) the loads of record j of the tile.  Exactly two load instructions are issued
 // whatever the record's length -- lanes past the end re-read the record's last chunk (same address,
-// no extra HBM traffic) -- so the compiler can retire them with counted waits (vmcnt(2)) while the
-// next record's pair is still in flight.  `live` = false issues the same two loads on the arena's
-// first chunk and marks the buffer unused.
+// no extra HBM traffic), an unused `head` reads the arena's first chunk -- so the compiler can retire
+// them with counted waits (vmcnt(2)) while the next record's pair is still in flight.  `live` = false
+// issues the same two loads on the arena's first chunk and marks the buffer unused.
+//
+// Cache policy: the 128-byte line a record ends in is shared with the next record, which the same wave
+// reads next.  The load that holds the record's end (`tail`) therefore uses the default policy, so that
+// line is still in L2 then; `head` ends inside the record and streams past the cache (non-temporal).
 __device__ __forceinline__ Rows2 issue_rows(const Batch& b, u32 my_len, u32 my_slot, u32 lane, u32 j, bool live) {
     Rows2 x;
     x.j = j;
@@ -109,8 +117,10 @@ __device__ __forceinline__ Rows2 issue_rows(const Batch& b, u32 my_len, u32 my_s
     x.nch = live ? (x.flen + 15u) >> 4 : 0u;
     x.p = reinterpret_cast<const u32x4*>(b.arena + (live ? (u64)slot * 16u : 0ull));
     const u32 last = x.nch != 0u ? x.nch - 1u : 0u;
-    x.r0 = ld_row(x.p + min(lane, last));
-    x.r1 = ld_row(x.p + min(lane + kWave, last));
+    const bool two = x.two();
+    const u32x4* hp = two ? x.p : reinterpret_cast<const u32x4*>(b.arena);
+    x.head = ld_row(hp + (two ? lane : 0u));
+    x.tail = x.p[min(lane + x.tail_base(), last)];
     return x;
 }
 
@@ -122,28 +132,39 @@ __device__ __forceinline__ u32x4 zero_unless(u32x4 v, bool keep) {
     return v;
 }
 
+__device__ __forceinline__ u32x4 pick_chunk(bool first, u32x4 a, u32x4 b) {
+    return u32x4{first ? a.x : b.x, first ? a.y : b.y, first ? a.z : b.z, first ? a.w : b.w};
+}
+
 // Sum of the full chunks of one streamed record (wave-uniform result); parks header and tail chunk.
 template <bool PARK_HDR>
 __device__ __forceinline__ u32 stream_one(const Rows2& cur, u32 lane, u32x4* __restrict__ park) {
     const u32 nfull = cur.flen >> 4;              // chunks that are summed whole
     const bool partial = (cur.flen & 15u) != 0u;  // chunk `nfull` exists and is cut short
+    const bool two = cur.two();
+    const u32 i1 = lane + cur.tail_base();        // chunk held by this lane's `tail`
     u32x4* mine = park + cur.j * kLdsChunksPerRec;
-    if (PARK_HDR && lane < kHdrChunks) mine[lane] = cur.r0;
-    const u32 i0 = lane, i1 = lane + kWave;
-    if (partial && nfull < kWave) {
-        if (i0 == nfull) mine[kHdrChunks] = cur.r0;
-    } else if (partial && nfull < 2u * kWave) {
-        if (i1 == nfull) mine[kHdrChunks] = cur.r1;
-    }
-    u32x4 a = cur.r0, c = cur.r1;
-    if (nfull < kWave) a = zero_unless(a, i0 < nfull);
-    if (nfull < 2u * kWave) c = zero_unless(c, i1 < nfull);
+    if (PARK_HDR && lane < kHdrChunks) mine[lane] = pick_chunk(two, cur.head, cur.tail);
+    // a cut chunk inside the first 2 KiB always sits in `tail` (`head` is only used when it is full)
+    if (partial && nfull < cur.tail_base() + kWave && i1 == nfull) mine[kHdrChunks] = cur.tail;
+    const u32x4 a = zero_unless(cur.head, two);
+    const u32x4 c = zero_unless(cur.tail, i1 < nfull);
     u32 acc = sum_chunk(a, 0u);
     acc = sum_chunk(c, acc);
     // beyond 2 KiB: four 1 KiB loads in flight per step, full chunks only (the cut chunk of such a
-    // record is fetched by its own lane afterwards)
+    // record is fetched by its own lane afterwards).  Whole steps stream past the cache; the last,
+    // partial step holds the record's end and uses the default policy like `tail`.
+    u32 c0 = 2u * kWave;
 #pragma nounroll
-    for (u32 c0 = 2u * kWave; c0 < nfull; c0 += 4u * kWave) {
+    for (; c0 + 4u * kWave <= nfull; c0 += 4u * kWave) {
+        const u32x4* q = cur.p + c0 + lane;
+        const u32x4 v0 = ld_stream(q), v1 = ld_stream(q + kWave), v2 = ld_stream(q + 2u * kWave), v3 = ld_stream(q + 3u * kWave);
+        acc = sum_chunk(v0, acc);
+        acc = sum_chunk(v1, acc);
+        acc = sum_chunk(v2, acc);
+        acc = sum_chunk(v3, acc);
+    }
+    if (c0 < nfull) {
         const u32 k0 = c0 + lane, k1 = k0 + kWave, k2 = k1 + kWave, k3 = k2 + kWave;
         u32x4 v0 = {0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
         if (k0 < nfull) v0 = ld_far(cur.p + k0);
@@ -477,12 +498,19 @@ __device__ __forceinline__ void tx_store(u32x4 v, u32x4* p) {
 #endif
 }
 
+struct TxRows {
+    u32x4 r0, r1;
+    const u32x4* p;
+    u32 flen, nch, j;
+    bool live;
+};
+
 // Rows 0/1 of a payload, loaded SH lanes to the right: lane L holds payload chunk L - SH (row 0) and
 // L + 64 - SH (row 1), so that lane L ends up owning output chunk L (L + 64) of the packet.  Exactly two
 // unconditional, clamped load instructions, as in issue_rows.
 template <u32 SH>
-__device__ __forceinline__ Rows2 issue_rows_shifted(const Batch& b, u32 my_len, u32 my_slot, u32 lane, u32 j, bool live) {
-    Rows2 x;
+__device__ __forceinline__ TxRows issue_rows_shifted(const Batch& b, u32 my_len, u32 my_slot, u32 lane, u32 j, bool live) {
+    TxRows x;
     x.j = j;
     x.live = live;
     x.flen = rdlane(my_len, j);
@@ -503,7 +531,7 @@ __device__ __forceinline__ Rows2 issue_rows_shifted(const Batch& b, u32 my_len, 
 // Returns nothing: rows 0/1 are stored last, whole, once the payload's sum has completed the L4 checksum
 // (the last 16-bit word of virtual chunk SH-1 for UDP, the third-last for ICMP).
 template <int R, u32 SH>
-__device__ __forceinline__ void tx_build_one(const Rows2& cur, u32 lane, u32 frame_len, u32x4* __restrict__ pout,
+__device__ __forceinline__ void tx_build_one(const TxRows& cur, u32 lane, u32 frame_len, u32x4* __restrict__ pout,
                                              const u32x4* __restrict__ hdr, u32 l4_partial_be, bool udp) {
     const u32 nin = cur.nch, nout = (frame_len + 15u) >> 4;
     const TailMask tm(cur.flen, nin);
@@ -583,7 +611,7 @@ __global__ __launch_bounds__(kBlock) void k_tx_build(Batch pay, const TxDesc* __
     const bool my_go = t.lane < t.cnt && st == UNET_TX_OK_;
 
     u64 todo = __ballot(my_go);
-    Rows2 A, B, C;
+    TxRows A, B, C;
 #define UNET_NEXT(X)                                                                 \
     {                                                                                \
         const bool has = todo != 0ull;                                               \
