@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Bandwidth of k_verify / k_csum as a function of record size: packed arenas of equal-length random
+records (about 4 GiB each), HIP-event timing on the launch stream."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import unet_amd
+
+sizes = [int(x) for x in sys.argv[1:]] or [40, 64, 128, 144, 256, 576, 1024, 1040, 1500, 2048, 4096, 9000, 65535]
+ctx = unet_amd.Offload(0)
+st = torch.cuda.Stream()
+torch.cuda.set_stream(st)
+ifc = unet_amd.Iface(ext_tcp=True)
+total = 4 << 30
+buf = torch.randint(0, 2**31 - 1, (total // 4 + 16,), dtype=torch.int32, device="cuda").view(torch.uint8)
+out = []
+for L in sizes:
+    slots = (L + 15) // 16
+    n = min(total // (slots * 16), 1 << 26)
+    d_len = torch.full((n,), L, dtype=torch.int32, device="cuda")
+    d_out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    nbytes = n * slots * 16
+    row = {"len": L, "records": n}
+    for name in ("verify", "csum"):
+        def run():
+            if name == "verify":
+                ctx.verify_dev(buf.data_ptr(), nbytes, None, slots, d_len.data_ptr(), n, ifc, d_out.data_ptr(), st.cuda_stream)
+            else:
+                ctx.csum_batch_dev(buf.data_ptr(), nbytes, None, slots, d_len.data_ptr(), None, n, d_out.data_ptr(), st.cuda_stream)
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        row[name + "_GBps"] = round(n * (L + 8) / ms / 1e6, 1)
+        row[name + "_Gpkt_s"] = round(n / ms / 1e6, 3)
+    out.append(row)
+    print(json.dumps(row), flush=True)

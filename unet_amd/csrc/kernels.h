@@ -30,6 +30,9 @@ struct Batch {
 // 64..9000-byte mix: 6.1 TB/s against 5.7 TB/s all non-temporal; 1500-byte packets are unaffected).
 // Knob for experiments (bit set = non-temporal): 1 rows 0/1 of a streamed record, 2 lane-parallel
 // records, 4 the loop past 2 KiB.  ld_stream() is always non-temporal (bandwidth yardstick).
+#ifndef UNET_MID_PATH
+#define UNET_MID_PATH 1
+#endif
 #ifndef UNET_NT_MASK
 #define UNET_NT_MASK 1
 #endif
@@ -51,9 +54,15 @@ __device__ __forceinline__ u32x4 ld_far(const u32x4* p) { return (UNET_NT_MASK &
 //     afterwards every lane adds the byte-masked tail chunk of its streamed record.
 // Callers then run their O(1)-per-record logic lane-parallel on headers read back from LDS, i.e. once
 // per tile on the vector unit instead of once per record on the (per-CU, shared) scalar unit.
-constexpr u32 kSmallChunks = 8;   // records <= 128 bytes are handled by a single lane
+#ifndef UNET_SMALL_CHUNKS
+#define UNET_SMALL_CHUNKS 12  // measured break-even with the 16-lane-row path: 192 bytes
+#endif
+constexpr u32 kSmallChunks = UNET_SMALL_CHUNKS;  // records of up to this many chunks are handled by a single lane
 constexpr u32 kHdrChunks = 6;     // 96 bytes: 14 (Ethernet) + 60 (max IPv4 header) + 16 (deepest L4 field) = 90
-constexpr u32 kLdsChunksPerRec = kHdrChunks + 1;  // + the record's partial last chunk
+// + the record's partial last chunk.  7 chunks = 28 dwords: lanes writing the same chunk of their own
+// records spread over the LDS banks (a power-of-two stride would put them all on the same few).
+constexpr u32 kLdsChunksPerRec = kHdrChunks + 1;
+constexpr u32 kMidChunks = 64;    // longer records up to 64 chunks (1024 bytes) are handled by a 16-lane row
 
 // Header dwords of a lane's own record, parked in LDS.
 struct LdsFetch {
@@ -87,16 +96,18 @@ struct Tile {
     }
 };
 
-// Up to 2 KiB of one record, as loaded by a whole wave: `tail` always holds the record's end (or its
-// chunks 64..127 when the record goes on past 2 KiB), `head` holds chunks 0..63 of a record longer than
-// 1 KiB and is a dummy otherwise.
+// The two ends of one record, as loaded by a whole wave: `tail` always holds the record's end (its last
+// 64 chunks when the record is longer than 2 KiB, chunks 64.. when it is longer than 1 KiB, all of it
+// otherwise), `head` holds chunks 0..63 of a record longer than 1 KiB and is a dummy otherwise.  What
+// lies between the two in a record longer than 2 KiB is read by stream_one itself.
 struct Rows2 {
     u32x4 head, tail;
     const u32x4* p;
     u32 flen, nch, j;
     bool live;
     __device__ __forceinline__ bool two() const { return nch > kWave; }           // head is in use
-    __device__ __forceinline__ u32 tail_base() const { return two() ? kWave : 0u; }  // chunk index of tail's lane 0
+    // chunk index of tail's lane 0
+    __device__ __forceinline__ u32 tail_base() const { return nch > 2u * kWave ? nch - kWave : (two() ? kWave : 0u); }
 };
 
 // Issue (not wait for) the loads of record j of the tile.  Exactly two load instructions are issued
@@ -145,18 +156,17 @@ __device__ __forceinline__ u32 stream_one(const Rows2& cur, u32 lane, u32x4* __r
     const u32 i1 = lane + cur.tail_base();        // chunk held by this lane's `tail`
     u32x4* mine = park + cur.j * kLdsChunksPerRec;
     if (PARK_HDR && lane < kHdrChunks) mine[lane] = pick_chunk(two, cur.head, cur.tail);
-    // a cut chunk inside the first 2 KiB always sits in `tail` (`head` is only used when it is full)
-    if (partial && nfull < cur.tail_base() + kWave && i1 == nfull) mine[kHdrChunks] = cur.tail;
+    // the cut chunk is the record's last one: always in `tail`
+    if (partial && i1 == nfull) mine[kHdrChunks] = cur.tail;
     const u32x4 a = zero_unless(cur.head, two);
     const u32x4 c = zero_unless(cur.tail, i1 < nfull);
     u32 acc = sum_chunk(a, 0u);
     acc = sum_chunk(c, acc);
-    // beyond 2 KiB: four 1 KiB loads in flight per step, full chunks only (the cut chunk of such a
-    // record is fetched by its own lane afterwards).  Whole steps stream past the cache; the last,
-    // partial step holds the record's end and uses the default policy like `tail`.
-    u32 c0 = 2u * kWave;
+    // between head and tail (records longer than 2 KiB): four 1 KiB streaming loads in flight per step
+    const u32 mid_end = cur.tail_base();
+    u32 c0 = kWave;
 #pragma nounroll
-    for (; c0 + 4u * kWave <= nfull; c0 += 4u * kWave) {
+    for (; c0 + 4u * kWave <= mid_end; c0 += 4u * kWave) {
         const u32x4* q = cur.p + c0 + lane;
         const u32x4 v0 = ld_stream(q), v1 = ld_stream(q + kWave), v2 = ld_stream(q + 2u * kWave), v3 = ld_stream(q + 3u * kWave);
         acc = sum_chunk(v0, acc);
@@ -164,13 +174,13 @@ __device__ __forceinline__ u32 stream_one(const Rows2& cur, u32 lane, u32x4* __r
         acc = sum_chunk(v2, acc);
         acc = sum_chunk(v3, acc);
     }
-    if (c0 < nfull) {
+    if (c0 < mid_end) {
         const u32 k0 = c0 + lane, k1 = k0 + kWave, k2 = k1 + kWave, k3 = k2 + kWave;
         u32x4 v0 = {0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
-        if (k0 < nfull) v0 = ld_far(cur.p + k0);
-        if (k1 < nfull) v1 = ld_far(cur.p + k1);
-        if (k2 < nfull) v2 = ld_far(cur.p + k2);
-        if (k3 < nfull) v3 = ld_far(cur.p + k3);
+        if (k0 < mid_end) v0 = ld_stream(cur.p + k0);
+        if (k1 < mid_end) v1 = ld_stream(cur.p + k1);
+        if (k2 < mid_end) v2 = ld_stream(cur.p + k2);
+        if (k3 < mid_end) v3 = ld_stream(cur.p + k3);
         acc = sum_chunk(v0, acc);
         acc = sum_chunk(v1, acc);
         acc = sum_chunk(v2, acc);
@@ -221,6 +231,86 @@ struct LaneTail {
     }
 };
 
+__device__ __forceinline__ u32 from_lane(u32 v, u32 src_lane) {
+    return (u32)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
+}
+
+// Records of kSmallChunks+1..64 chunks: four at a time, one per 16-lane row of the wave (a whole wave on one such
+// record would leave most lanes idle).  Every lane issues exactly four loads -- chunks sub, sub+16,
+// sub+32, sub+48 of its row's record, clamped to the last chunk -- with the default cache policy (each
+// holds or neighbours a record end).  Two groups of four are in flight: the next group's loads go out
+// before the current one is summed.  A row's sum of full chunks is reduced with four row_shr steps and
+// left in `sums[record]`; the first six chunks and the cut chunk go to the record's LDS area.
+struct MidGroup {
+    u32x4 v0, v1, v2, v3;
+    u32 rec, len;   // per 16-lane row
+    bool row_live;  // per 16-lane row
+    bool any;       // wave-uniform: the group holds at least one record
+};
+
+__device__ __forceinline__ MidGroup issue_mid(const Batch& b, const Tile& t, u64& mid) {
+    const u32 sub = t.lane & 15u, q = t.lane >> 4;
+    MidGroup g;
+    g.any = mid != 0ull;
+    u32 r[4];
+    bool have[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        have[k] = mid != 0ull;
+        r[k] = have[k] ? (u32)__builtin_ctzll(mid) : 0u;
+        mid &= mid - 1ull;  // stays 0 once empty
+    }
+    g.rec = q == 0u ? r[0] : (q == 1u ? r[1] : (q == 2u ? r[2] : r[3]));
+    g.row_live = q == 0u ? have[0] : (q == 1u ? have[1] : (q == 2u ? have[2] : have[3]));
+    g.len = from_lane(t.my_len, g.rec);
+    const u32 slot = from_lane(t.my_slot, g.rec);
+    const u32 nch = g.row_live ? (g.len + 15u) >> 4 : 0u;
+    const u32 last = nch != 0u ? nch - 1u : 0u;
+    const u32x4* p = reinterpret_cast<const u32x4*>(b.arena + (g.row_live ? (u64)slot * 16u : 0ull));
+    g.v0 = p[min(sub, last)];
+    g.v1 = p[min(sub + 16u, last)];
+    g.v2 = p[min(sub + 32u, last)];
+    g.v3 = p[min(sub + 48u, last)];
+    return g;
+}
+
+template <bool PARK_HDR>
+__device__ __forceinline__ void consume_mid(const MidGroup& g, u32 lane, u32x4* __restrict__ park, u32* __restrict__ sums) {
+    const u32 sub = lane & 15u;
+    const u32 nfull = g.row_live ? g.len >> 4 : 0u;
+    u32x4* mine = park + g.rec * kLdsChunksPerRec;
+    if (PARK_HDR && g.row_live && sub < kHdrChunks) mine[sub] = g.v0;
+    if (g.row_live && (g.len & 15u) != 0u && sub == (nfull & 15u)) {
+        const u32 w = nfull >> 4;  // which of the four loads holds the cut chunk
+        mine[kHdrChunks] = w == 0u ? g.v0 : (w == 1u ? g.v1 : (w == 2u ? g.v2 : g.v3));
+    }
+    u32 acc = sum_chunk(zero_unless(g.v0, sub < nfull), 0u);
+    acc = sum_chunk(zero_unless(g.v1, sub + 16u < nfull), acc);
+    acc = sum_chunk(zero_unless(g.v2, sub + 32u < nfull), acc);
+    acc = sum_chunk(zero_unless(g.v3, sub + 48u < nfull), acc);
+    acc = dpp_add<0x111, 0xf>(acc);  // row_shr:1
+    acc = dpp_add<0x112, 0xf>(acc);  // row_shr:2
+    acc = dpp_add<0x114, 0xf>(acc);  // row_shr:4
+    acc = dpp_add<0x118, 0xf>(acc);  // row_shr:8 -> lane 15 of the row holds the row's sum
+    if (g.row_live && sub == 15u) sums[g.rec] = acc;
+}
+
+template <bool PARK_HDR>
+__device__ __forceinline__ void mid_records(const Batch& b, const Tile& t, u64 mid, u32x4* __restrict__ park,
+                                            u32* __restrict__ sums) {
+    if (mid == 0ull) return;
+    MidGroup g0 = issue_mid(b, t, mid), g1;
+#pragma nounroll
+    while (true) {
+        g1 = issue_mid(b, t, mid);
+        consume_mid<PARK_HDR>(g0, t.lane, park, sums);
+        if (!g1.any) break;
+        g0 = issue_mid(b, t, mid);
+        consume_mid<PARK_HDR>(g1, t.lane, park, sums);
+        if (!g0.any) break;
+    }
+}
+
 // Exact sum of the lane's own record (0 for lanes without a valid record).  On return the wave's LDS
 // area `park` holds, for record j, chunks 0..5 at park[j*7 .. j*7+5] (if PARK_HDR) -- visible to every
 // lane of the wave.
@@ -229,12 +319,17 @@ __device__ __forceinline__ u32 tile_sums(const Batch& b, const Tile& t, u32x4* _
     u32x4* mine = park + t.lane * kLdsChunksPerRec;  // only meaningful for lane < TILE
     const u32 my_nch = t.my_ok ? (t.my_len + 15u) >> 4 : 0u;
     const bool my_small = t.my_ok && my_nch >= 1u && my_nch <= kSmallChunks;
-    const bool my_big = t.my_ok && my_nch > kSmallChunks;
+    const bool my_mid = UNET_MID_PATH && t.my_ok && my_nch > kSmallChunks && my_nch <= kMidChunks;
+    const bool my_big = t.my_ok && my_nch > kSmallChunks && !my_mid;
     const LaneTail tail(t.my_len);
     const bool my_partial = (t.my_len & 15u) != 0u;
     u32 my_total = 0;
 
-    // ---- streamed records: the first loads go out before anything else
+    // ---- mid-size records (up to 1 KiB), four at a time (its register buffers are free again afterwards)
+    u32* sums = reinterpret_cast<u32*>(park + TILE * kLdsChunksPerRec);  // one u32 per record of the tile
+    if (UNET_MID_PATH) mid_records<PARK_HDR>(b, t, __ballot(my_mid), park, sums);
+
+    // ---- streamed records: their first loads go out before the lane-parallel part
     u64 todo = __ballot(my_big);
 #ifndef UNET_DEPTH
 #define UNET_DEPTH 3  // register buffers in rotation: two records' loads in flight while a third is summed
@@ -259,13 +354,7 @@ __device__ __forceinline__ u32 tile_sums(const Batch& b, const Tile& t, u32x4* _
 #endif
     }
 
-    // ---- the cut last chunk of a record longer than 2 KiB is not held in rows 0/1: its own lane
-    // fetches it now, long before it is needed
-    const bool my_far = my_big && my_partial && (t.my_len >> 4) >= 2u * kWave;
-    u32x4 far_cut = {0, 0, 0, 0};
-    if (my_far) far_cut = ld_far(reinterpret_cast<const u32x4*>(b.arena + (u64)t.my_slot * 16u) + (t.my_len >> 4));
-
-    // ---- lane-parallel records: each lane pulls its own 1..8 chunks.  Straight-line code per group
+    // ---- lane-parallel records: each lane pulls its own 1..kSmallChunks chunks.  Straight-line code per group
     // of four: unconditional loads (indices past the end re-read the last chunk and are zeroed by
     // selects), so all of them are in flight together and no wide value is merged across branches.
     if (my_small) {
@@ -291,6 +380,18 @@ __device__ __forceinline__ u32 tile_sums(const Batch& b, const Tile& t, u32x4* _
             UNET_SMALL_LOAD(4); UNET_SMALL_LOAD(5); UNET_SMALL_LOAD(6); UNET_SMALL_LOAD(7);
             UNET_SMALL_USE(4) UNET_SMALL_USE(5) UNET_SMALL_USE(6) UNET_SMALL_USE(7)
         }
+#if UNET_SMALL_CHUNKS > 8
+        if (last >= 8u) {
+            UNET_SMALL_LOAD(8); UNET_SMALL_LOAD(9); UNET_SMALL_LOAD(10); UNET_SMALL_LOAD(11);
+            UNET_SMALL_USE(8) UNET_SMALL_USE(9) UNET_SMALL_USE(10) UNET_SMALL_USE(11)
+        }
+#endif
+#if UNET_SMALL_CHUNKS > 12
+        if (last >= 12u) {
+            UNET_SMALL_LOAD(12); UNET_SMALL_LOAD(13); UNET_SMALL_LOAD(14); UNET_SMALL_LOAD(15);
+            UNET_SMALL_USE(12) UNET_SMALL_USE(13) UNET_SMALL_USE(14) UNET_SMALL_USE(15)
+        }
+#endif
         UNET_SMALL_USE(0) UNET_SMALL_USE(1) UNET_SMALL_USE(2) UNET_SMALL_USE(3)
 #undef UNET_SMALL_LOAD
 #undef UNET_SMALL_USE
@@ -333,17 +434,19 @@ __device__ __forceinline__ u32 tile_sums(const Batch& b, const Tile& t, u32x4* _
     // ---- LDS written by other lanes of this wave is read back below and by the caller
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (my_big && my_partial) {
-        const u32 nfull = t.my_len >> 4;
-        // parked by the wave while it held rows 0/1, or fetched by this lane at the top
-        const u32x4 cut = nfull < 2u * kWave ? mine[kHdrChunks] : far_cut;
-        my_total = sum_chunk(tail.apply(cut), my_total);
+    if (my_mid) my_total = sums[t.lane];
+    if ((my_big || my_mid) && my_partial) {
+        // parked by the wave while it held the record's last row
+        my_total = sum_chunk(tail.apply(mine[kHdrChunks]), my_total);
     }
     return my_total;
 }
 
-#define UNET_TILE_LDS(TILE) __shared__ u32x4 lds[(kBlock / kWave) * (TILE) * kLdsChunksPerRec]; \
-    u32x4* park = lds + (threadIdx.x >> 6) * ((TILE) * kLdsChunksPerRec)
+// Per wave: TILE record areas of kLdsChunksPerRec chunks, then TILE u32 sums (TILE/4 chunks, at least one).
+#define UNET_TILE_LDS(TILE)                                                                         \
+    constexpr u32 kWaveLds = (TILE) * kLdsChunksPerRec + ((TILE) + 3u) / 4u;                        \
+    __shared__ u32x4 lds[(kBlock / kWave) * kWaveLds];                                              \
+    u32x4* park = lds + (threadIdx.x >> 6) * kWaveLds
 
 // ---------------------------------------------------------------- a1: calculate_checksum
 // out[i] = calculate_checksum(record i, seeds[i])  (src/utils.rs:1-17)
@@ -413,6 +516,37 @@ __global__ __launch_bounds__(kBlock) void k_ipv4_validate(const uint8_t* __restr
             for (u32 h = h0; h < n; ++h, w += 5) out[h] = ipv4_header_verdict(w[0], w[1], w[2], w[3], w[4], ext_tcp);
         }
     }
+}
+
+// Same verdicts for whole groups of 256 headers per wave (1024 per workgroup): the 5 KiB of a group are
+// pulled with five fully coalesced, streaming 1 KiB loads, turned through the wave's LDS area so that
+// each lane gets the five chunks of its own four headers, and answered with one coalesced 1 KiB store.
+constexpr u32 kHdrPerWave = kWave * kHdrPerGroup;          // 256 headers
+constexpr u32 kHdrChunksPerWave = kHdrPerWave * 20u / 16u;  // 320 chunks
+
+__global__ __launch_bounds__(kBlock) void k_ipv4_validate_rows(const u32x4* __restrict__ hdr_chunks, u32 ext_tcp,
+                                                               u32x4* __restrict__ out4) {
+    __shared__ u32x4 lds[(kBlock / kWave) * kHdrChunksPerWave];
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    u32x4* mine = lds + wave * kHdrChunksPerWave;
+    const u64 g = (u64)blockIdx.x * (kBlock / kWave) + wave;
+    const u32x4* src = hdr_chunks + g * kHdrChunksPerWave + lane;
+    u32x4 v[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = ld_stream(src + k * kWave);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) mine[k * kWave + lane] = v[k];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    u32x4 d[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) d[k] = mine[lane * 5u + k];
+    u32x4 r;
+    r.x = ipv4_header_verdict(d[0].x, d[0].y, d[0].z, d[0].w, d[1].x, ext_tcp);
+    r.y = ipv4_header_verdict(d[1].y, d[1].z, d[1].w, d[2].x, d[2].y, ext_tcp);
+    r.z = ipv4_header_verdict(d[2].z, d[2].w, d[3].x, d[3].y, d[3].z, ext_tcp);
+    r.w = ipv4_header_verdict(d[3].w, d[4].x, d[4].y, d[4].z, d[4].w, ext_tcp);
+    __builtin_nontemporal_store(r, out4 + g * kWave + lane);
 }
 
 // ------------------------------- a7, a9, a10: transmit-side checksum fill, in place

@@ -313,10 +313,19 @@ int unet_ipv4_validate_dev(unet_ctx* ctx, void* stream, const uint8_t* d_hdrs, u
     if (((uintptr_t)d_hdrs & 15u) != 0) return fail(UNET_E_INVAL, "header buffer must be 16-byte aligned");
     HIP_TRY(hipSetDevice(ctx->device));
     if (((uintptr_t)d_out & 15u) != 0) return fail(UNET_E_INVAL, "result buffer must be 16-byte aligned");
-    const u32 per_block = kBlock * kHdrPerGroup;
-    const u32 grid = (n + per_block - 1) / per_block;
-    hipLaunchKernelGGL(k_ipv4_validate, dim3(grid), dim3(kBlock), 0, pick(ctx, stream), d_hdrs, n,
-                       iface->ext_tcp ? 1u : 0u, (u32*)d_out);
+    const u32 ext = iface->ext_tcp ? 1u : 0u;
+    // whole workgroups of 1024 headers take the row kernel; the remainder (< 1024) the per-lane kernel
+    const u32 per_block = (kBlock / kWave) * kHdrPerWave;
+    const u32 full_blocks = getenv("UNET_HDR_PLAIN") ? 0u : n / per_block;
+    const u32 done = full_blocks * per_block;
+    if (full_blocks)
+        hipLaunchKernelGGL(k_ipv4_validate_rows, dim3(full_blocks), dim3(kBlock), 0, pick(ctx, stream), (const u32x4*)d_hdrs, ext,
+                           (u32x4*)d_out);
+    if (n > done) {
+        const u32 rest = n - done, per = kBlock * kHdrPerGroup;
+        hipLaunchKernelGGL(k_ipv4_validate, dim3((rest + per - 1) / per), dim3(kBlock), 0, pick(ctx, stream),
+                           d_hdrs + (size_t)done * 20u, rest, ext, (u32*)d_out + done);
+    }
     HIP_TRY(hipGetLastError());
     return UNET_OK;
 }
