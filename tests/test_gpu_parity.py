@@ -304,6 +304,40 @@ def test_ipv4_validate_device_generated(offload):
     assert (results_to_numpy(d_out) == O.ipv4_validate_batch(h_arena[:n * 20])).all()
 
 
+def test_scattered_and_shared_slots(offload):
+    """Nothing may depend on records being packed in order: slots are shuffled, separated by gaps of garbage,
+    and some records share one slot (the same bytes judged twice, and a shorter record that is a prefix of
+    a longer one)."""
+    rng = np.random.default_rng(77)
+    ifc = unet_amd.Iface(ext_tcp=True)
+    n = 6000
+    h_arena, off16, lens = unet_amd.synth_host(unet_amd.SYNTH_IMIX, SEED, 31337, n, ifc)
+    slots = (lens.astype(np.int64) + 15) // 16
+    order = rng.permutation(n)
+    gaps = rng.integers(0, 9, size=n)
+    new_off = np.zeros(n, dtype=np.int64)
+    pos = 3
+    for i in order:
+        new_off[i] = pos
+        pos += int(slots[i]) + int(gaps[i])
+    arena = rng.integers(0, 256, size=(pos + 4) * 16, dtype=np.uint8)
+    for i in range(n):
+        a, b = int(off16[i]) * 16, int(new_off[i]) * 16
+        arena[b:b + int(lens[i])] = h_arena[a:a + int(lens[i])]
+    # aliases: record i judged again in full, and as a truncated prefix
+    dup = rng.integers(0, n, size=500)
+    cut = rng.integers(0, n, size=500)
+    all_off = np.concatenate([new_off, new_off[dup], new_off[cut]]).astype(np.uint32)
+    all_len = np.concatenate([lens, lens[dup], (lens[cut] * rng.random(500)).astype(np.uint32)]).astype(np.uint32)
+    perm = rng.permutation(len(all_len))
+    all_off, all_len = all_off[perm], all_len[perm]
+    got = offload.verify(arena, all_off, all_len, ifc)
+    exp = O.recv_batch(arena, all_off, all_len, ifc)
+    bad = np.nonzero(got != exp)[0]
+    assert bad.size == 0, (bad[:5], got[bad[:5]], exp[bad[:5]], all_len[bad[:5]])
+    assert (offload.csum_batch(arena, all_off, all_len) == O.csum_batch(arena, all_off, all_len)).all()
+
+
 # ------------------------------------------------------------------ a7, a9, a10: transmit side
 
 def test_generate_matches_oracle_and_roundtrips(offload):

@@ -102,6 +102,7 @@ struct Tile {
 // lies between the two in a record longer than 2 KiB is read by stream_one itself.
 struct Rows2 {
     u32x4 head, tail;
+
     const u32x4* p;
     u32 flen, nch, j;
     bool live;
