@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Bandwidth of k_tx_build as a function of payload size (UDP, L3 and L2 output), HIP-event timing."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import unet_amd
+from unet_amd._ffi import TX_DESC_DTYPE, tx_frame_len
+
+sizes = [int(x) for x in sys.argv[1:]] or [18, 64, 128, 256, 548, 1000, 1472, 4000, 8972, 65507]
+ctx = unet_amd.Offload(0)
+st = torch.cuda.Stream()
+torch.cuda.set_stream(st)
+total = 2 << 30
+buf = torch.randint(0, 2**31 - 1, (total // 4 + 16,), dtype=torch.int32, device="cuda").view(torch.uint8)
+for mode in (0, 1):
+    ifc = unet_amd.Iface(mode=mode)
+    for L in sizes:
+        slots = max(1, (L + 15) // 16)
+        n = min(total // (slots * 16), 1 << 24)
+        flen = int(tx_frame_len(L, mode))
+        oslots = (flen + 15) // 16
+        desc = np.zeros(n, dtype=TX_DESC_DTYPE)
+        desc["src"], desc["dst"], desc["proto"], desc["l4a"], desc["l4b"] = ifc.unicast, 0xC6336407, 17, 1234, 4321
+        desc["ip_id"] = np.arange(n) & 0xFFFF
+        d_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1)).cuda()
+        d_plen = torch.full((n,), L, dtype=torch.int32, device="cuda")
+        d_ooff = (torch.arange(n, dtype=torch.int64, device="cuda") * oslots).to(torch.int32)
+        d_out = torch.empty(n * oslots * 16 + 16, dtype=torch.uint8, device="cuda")
+        d_olen = torch.zeros(n, dtype=torch.int32, device="cuda")
+        d_st = torch.zeros(n, dtype=torch.uint8, device="cuda")
+
+        def run():
+            ctx.tx_build_dev(buf.data_ptr(), n * slots * 16, None, slots, d_plen.data_ptr(), d_desc.data_ptr(), n, ifc, d_out.data_ptr(),
+                             n * oslots * 16, d_ooff.data_ptr(), d_olen.data_ptr(), d_st.data_ptr(), st.cuda_stream)
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        assert int(d_st.max().item()) == 0 and int(d_olen.min().item()) == flen
+        print(json.dumps({"mode": "L2" if mode else "L3", "payload": L, "packet": flen, "packets": n,
+                          "GBps": round(n * (L + flen + 41) / ms / 1e6, 1), "Gpkt_s": round(n / ms / 1e6, 3)}), flush=True)
+        del d_out

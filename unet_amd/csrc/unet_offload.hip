@@ -444,13 +444,20 @@ int unet_tx_build_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload_aren
     HIP_TRY(hipSetDevice(ctx->device));
     Batch b{d_payload_arena, payload_arena_bytes, d_payload_off16, payload_stride16, d_payload_len, n};
     const IfaceDev ifc = to_dev(iface);
-    constexpr int T = 16;
-    if (iface->mode == UNET_MODE_L2)
-        hipLaunchKernelGGL((k_tx_build<MODE_L2, T>), dim3(tiles_grid(n, T)), dim3(kBlock), 0, pick(ctx, stream), b, (const TxDesc*)d_desc,
-                           ifc, d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status);
-    else
-        hipLaunchKernelGGL((k_tx_build<MODE_L3, T>), dim3(tiles_grid(n, T)), dim3(kBlock), 0, pick(ctx, stream), b, (const TxDesc*)d_desc,
-                           ifc, d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status);
+#define UNET_TX_LAUNCH(M, T)                                                                                             \
+    hipLaunchKernelGGL((k_tx_build<M, T>), dim3(tiles_grid(n, T)), dim3(kBlock), 0, pick(ctx, stream), b, (const TxDesc*)d_desc, ifc, \
+                       d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status)
+    const int tile = pick_tile(payload_arena_bytes, n);
+    if (iface->mode == UNET_MODE_L2) {
+        if (tile == 16) UNET_TX_LAUNCH(MODE_L2, 16);
+        else if (tile == 32) UNET_TX_LAUNCH(MODE_L2, 32);
+        else UNET_TX_LAUNCH(MODE_L2, 64);
+    } else {
+        if (tile == 16) UNET_TX_LAUNCH(MODE_L3, 16);
+        else if (tile == 32) UNET_TX_LAUNCH(MODE_L3, 32);
+        else UNET_TX_LAUNCH(MODE_L3, 64);
+    }
+#undef UNET_TX_LAUNCH
     HIP_TRY(hipGetLastError());
     return UNET_OK;
 }
