@@ -318,7 +318,7 @@ def main():
     op = args.workload if args.workload in ("csum", "generate", "txbuild") else "verify"
     batches = [Batch(ctx, stream, kind, ifc, r * n_global, n_global, shard_world, shard_rank, stride16, op) for r in range(rotate)]
     b0 = batches[0]
-    kernel = {"csum": "k_csum", "generate": "k_generate", "txbuild": "k_tx_build<MODE_L3>"}.get(op, "k_ipv4_validate" if kind == unet_amd.SYNTH_IPV4_HDR20 else "k_verify<MODE_L3>")
+    kernel = {"csum": "k_csum", "generate": "k_generate", "txbuild": "k_tx_build<MODE_L3>"}.get(op, "k_ipv4_validate_rows" if kind == unet_amd.SYNTH_IPV4_HDR20 else "k_verify<MODE_L3>")
     torch.cuda.synchronize()
 
     # ---- timed region
