@@ -46,6 +46,7 @@ WORKLOADS = {
     "csum": (unet_amd.SYNTH_UDP1500, 1 << 22, 94),
     "generate": (unet_amd.SYNTH_UDP1500, 1 << 22, 94),
     "txbuild": (unet_amd.SYNTH_UDP1500, 1 << 22, 94),
+    "eth1514": (unet_amd.SYNTH_UDP1500, 1 << 22, 94),
 }
 DESCRIPTION = {
     "udp1500": "4,194,304 x 1500-byte IPv4/UDP packets per GPU (BASELINE configs[2])",
@@ -55,6 +56,7 @@ DESCRIPTION = {
     "csum": "calculate_checksum over 4,194,304 x 1500-byte records per GPU (unet_csum_batch_dev)",
     "generate": "transmit-side checksum fill of 4,194,304 x 1500-byte IPv4/UDP packets per GPU, in place (unet_generate_dev)",
     "txbuild": "4,194,304 x 1500-byte IPv4/UDP packets per GPU built from 1472-byte payloads + descriptors (unet_tx_build_dev)",
+    "eth1514": "4,194,304 x 1514-byte Ethernet frames per GPU (IPv4/UDP inside, built by unet_tx_build_dev in L2 mode, faults injected), judged in L2 mode",
 }
 
 
@@ -144,11 +146,15 @@ class Batch:
             self.alg_bytes -= 2 * self.n      # 2-byte results
         elif op == "generate":
             self.alg_bytes += self.n          # 4 bytes of checksum fields + 1 status byte instead of a 4-byte result
-        elif op == "txbuild":
+        elif op in ("txbuild", "eth1514"):
             # the resident records serve as 1472-byte payloads; every packet goes to one receiver address
             from unet_amd._ffi import TX_DESC_DTYPE
-            self.rx = unet_amd.Iface("198.51.100.7", "255.255.255.0")
+            l2 = op == "eth1514"
+            self.rx = unet_amd.Iface("198.51.100.7", "255.255.255.0", mac=bytes.fromhex("02c0ffee0007"), mode=1 if l2 else 0)
+            self.tx_ifc = ifc.replace(mode=1 if l2 else 0)
+            self.ostride = 95 if l2 else 94  # 1514 / 1500 bytes in 16-byte slots
             desc = np.zeros(self.n, dtype=TX_DESC_DTYPE)
+            desc["dst_mac"] = np.frombuffer(bytes(self.rx.mac), dtype=np.uint8)
             rng = np.random.default_rng(SEED + first_idx)
             desc["src"], desc["dst"], desc["proto"] = ifc.unicast, self.rx.unicast, 17
             desc["l4a"] = rng.integers(0, 65536, size=self.n)
@@ -156,13 +162,23 @@ class Batch:
             desc["ip_id"] = np.arange(self.n) & 0xFFFF
             self.desc = torch.from_numpy(desc.view(np.uint8).reshape(-1)).cuda()
             self.plen = torch.full((self.n,), 1472, dtype=torch.int32, device="cuda")
-            self.ooff = (torch.arange(self.n, dtype=torch.int64, device="cuda") * 94).to(torch.int32)
-            self.out_bytes = self.n * 94 * 16
+            self.ooff = (torch.arange(self.n, dtype=torch.int64, device="cuda") * self.ostride).to(torch.int32)
+            self.out_bytes = self.n * self.ostride * 16
             self.out_arena = torch.zeros(self.out_bytes + 16, dtype=torch.uint8, device="cuda")
             self.olen = torch.zeros(self.n, dtype=torch.int32, device="cuda")
             self.status = torch.zeros(self.n, dtype=torch.uint8, device="cuda")
             # payload + packet + descriptor + payload length, output offset, output length, status
             self.alg_bytes = self.n * (1472 + 1500 + 28 + 4 + 4 + 4 + 1)
+            if l2:
+                # build the frames once, then damage some: a payload byte (idx % 64 == 5), the destination MAC
+                # (idx % 128 == 9), the EtherType (idx % 256 == 77)
+                self.build()
+                fr = self.out_arena[:self.out_bytes].view(self.n, self.ostride * 16)
+                idx = torch.arange(self.n, device="cuda")
+                fr[idx % 64 == 5, 700] ^= 0x40
+                fr[idx % 128 == 9, 3] ^= 0x01
+                fr[idx % 256 == 77, 13] = 0x01
+                self.alg_bytes = self.n * (1514 + 4 + 4)  # frame + length + result
 
     def run(self):
         if self.op == "csum":
@@ -174,15 +190,21 @@ class Batch:
             self.ctx.generate_dev(self.arena.data_ptr(), self.nbytes, off_ptr, self.stride16, self.len.data_ptr(), self.n,
                                   self.out.data_ptr(), self.stream)
         elif self.op == "txbuild":
-            self.ctx.tx_build_dev(self.arena.data_ptr(), self.nbytes, None, 94, self.plen.data_ptr(), self.desc.data_ptr(), self.n,
-                                  self.ifc, self.out_arena.data_ptr(), self.out_bytes, self.ooff.data_ptr(), self.olen.data_ptr(),
-                                  self.status.data_ptr(), self.stream)
+            self.build()
+        elif self.op == "eth1514":
+            self.ctx.verify_dev(self.out_arena.data_ptr(), self.out_bytes, None, self.ostride, self.olen.data_ptr(), self.n, self.rx,
+                                self.out.data_ptr(), self.stream)
         elif self.kind == unet_amd.SYNTH_IPV4_HDR20:
             self.ctx.ipv4_validate_dev(self.arena.data_ptr(), self.n, self.ifc, self.out.data_ptr(), self.stream)
         else:
             off_ptr = None if self.stride16 else self.off.data_ptr()
             self.ctx.verify_dev(self.arena.data_ptr(), self.nbytes, off_ptr, self.stride16, self.len.data_ptr(), self.n,
                                 self.ifc, self.out.data_ptr(), self.stream)
+
+    def build(self):
+        self.ctx.tx_build_dev(self.arena.data_ptr(), self.nbytes, None, 94, self.plen.data_ptr(), self.desc.data_ptr(), self.n,
+                              self.tx_ifc, self.out_arena.data_ptr(), self.out_bytes, self.ooff.data_ptr(), self.olen.data_ptr(),
+                              self.status.data_ptr(), self.stream)
 
     def counts(self):
         d_cnt = torch.zeros(32, dtype=torch.int64, device="cuda")
@@ -315,10 +337,10 @@ def main():
     # rotated over several distinct batches (consecutive index ranges of the same trace) so that no
     # launch finds its input in cache.
     rotate = args.rotate if args.rotate else (6 if kind == unet_amd.SYNTH_IPV4_HDR20 else 1)
-    op = args.workload if args.workload in ("csum", "generate", "txbuild") else "verify"
+    op = args.workload if args.workload in ("csum", "generate", "txbuild", "eth1514") else "verify"
     batches = [Batch(ctx, stream, kind, ifc, r * n_global, n_global, shard_world, shard_rank, stride16, op) for r in range(rotate)]
     b0 = batches[0]
-    kernel = {"csum": "k_csum", "generate": "k_generate", "txbuild": "k_tx_build<MODE_L3>"}.get(op, "k_ipv4_validate_rows" if kind == unet_amd.SYNTH_IPV4_HDR20 else "k_verify<MODE_L3>")
+    kernel = {"csum": "k_csum", "generate": "k_generate", "txbuild": "k_tx_build<MODE_L3>", "eth1514": "k_verify<MODE_L2>"}.get(op, "k_ipv4_validate_rows" if kind == unet_amd.SYNTH_IPV4_HDR20 else "k_verify<MODE_L3>")
     torch.cuda.synchronize()
 
     # ---- timed region
@@ -342,7 +364,7 @@ def main():
     # ---- epilogue: per-verdict counters, summed across GPUs (the only cross-GPU traffic)
     if op == "txbuild":
         # judge the built packets as the receiver would: every one must be accepted
-        ctx.verify_dev(b0.out_arena.data_ptr(), b0.out_bytes, None, 94, b0.olen.data_ptr(), b0.n, b0.rx, b0.out.data_ptr(), stream)
+        ctx.verify_dev(b0.out_arena.data_ptr(), b0.out_bytes, None, b0.ostride, b0.olen.data_ptr(), b0.n, b0.rx, b0.out.data_ptr(), stream)
     if op == "csum":
         b0.out.zero_()  # 16-bit checksums are not verdicts: nothing to count
     d_cnt = b0.counts()
@@ -370,6 +392,14 @@ def main():
     if op == "txbuild":
         parity = bool(local_cnt[Verdict.ACCEPT_UDP] == b0.n and int(b0.status.max().item()) == 0
                       and int(b0.olen.min().item()) == 1500 == int(b0.olen.max().item()))
+    if op == "eth1514":
+        i = np.arange(b0.n)
+        bad_type = i % 256 == 77
+        bad_mac = (i % 128 == 9) & ~bad_type
+        bad_sum = (i % 64 == 5) & ~bad_type & ~bad_mac
+        parity = bool(local_cnt[Verdict.DROP_L2_ETHERTYPE] == bad_type.sum() and local_cnt[Verdict.DROP_L2_NOT_FOR_ME] == bad_mac.sum()
+                      and local_cnt[Verdict.DROP_UDP_CSUM] == bad_sum.sum()
+                      and local_cnt[Verdict.ACCEPT_UDP] == b0.n - bad_type.sum() - bad_mac.sum() - bad_sum.sum())
     if args.workload == "udp1500":
         # per-index fault rules of the trace: idx % 256 == 33 -> length mismatch; idx % 64 == 7 or
         # idx % 256 == 97 -> checksum failure (a zeroed field can verify only if the true value was 0)
@@ -381,6 +411,8 @@ def main():
 
     # ---- attainable-bandwidth yardstick: read-only streaming kernel over the same buffer
     d_sink = torch.zeros(4096, dtype=torch.int32, device="cuda")
+    if op == "eth1514":
+        b0.arena, b0.nbytes = b0.out_arena, b0.out_bytes  # the frames are what this workload reads
     for _ in range(2):
         ctx.stream_read_dev(b0.arena.data_ptr(), b0.nbytes, d_sink.data_ptr(), stream)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -562,6 +562,53 @@ def test_full_size_every_record_against_oracle(offload, kind, n, ext_tcp):
     assert len(set(got["verdict"].tolist())) >= (3 if kind == unet_amd.SYNTH_UDP1500 else 10)
 
 
+def test_full_size_ethernet_frames_every_record_against_oracle(offload):
+    """4,194,304 x 1514-byte Ethernet frames built on the GPU (unet_tx_build_dev, L2 mode) from generated
+    payloads, some damaged afterwards; every L2-mode verdict is compared with the CPU oracle's."""
+    torch = torch_mod()
+    from unet_amd._ffi import TX_DESC_DTYPE
+    n, pstride, ostride = 1 << 22, 92, 95
+    tx = unet_amd.Iface("192.0.2.2", "255.255.255.0", mac=bytes.fromhex("02aabbccddee"), mode=unet_amd.MODE_L2)
+    rx = unet_amd.Iface("198.51.100.7", "255.255.255.0", mac=bytes.fromhex("02c0ffee0007"), mode=unet_amd.MODE_L2)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    d_pay = torch.randint(0, 2**31 - 1, (n * pstride * 4,), dtype=torch.int32, device="cuda", generator=g).view(torch.uint8)
+    desc = np.zeros(n, dtype=TX_DESC_DTYPE)
+    desc["src"], desc["dst"], desc["proto"] = tx.unicast, rx.unicast, 17
+    desc["proto"][::5] = 1
+    desc["l4a"] = np.arange(n) & 0xFFFF
+    desc["l4a"][::5] = np.where(np.arange(0, n, 5) % 3 == 0, 0x0800, np.where(np.arange(0, n, 5) % 3 == 1, 0x0000, 0x0300))
+    desc["l4b"], desc["ip_id"] = 53, np.arange(n) & 0xFFFF
+    desc["dst_mac"] = np.frombuffer(bytes(rx.mac), dtype=np.uint8)
+    d_desc = dev(desc.view(np.uint8).reshape(-1))
+    d_plen = torch.full((n,), 1472, dtype=torch.int32, device="cuda")
+    d_ooff = (torch.arange(n, dtype=torch.int64, device="cuda") * ostride).to(torch.int32)
+    obytes = n * ostride * 16
+    d_out = torch.zeros(obytes, dtype=torch.uint8, device="cuda")
+    d_olen = torch.zeros(n, dtype=torch.int32, device="cuda")
+    offload.tx_build_dev(d_pay.data_ptr(), d_pay.numel(), None, pstride, d_plen.data_ptr(), d_desc.data_ptr(), n, tx, d_out.data_ptr(),
+                         obytes, d_ooff.data_ptr(), d_olen.data_ptr(), None, stream())
+    torch.cuda.synchronize()
+    assert int(d_olen.min().item()) == 1514 == int(d_olen.max().item())
+    fr = d_out.view(n, ostride * 16)
+    idx = torch.arange(n, device="cuda")
+    fr[idx % 64 == 5, 700] ^= 0x40
+    fr[idx % 128 == 9, 3] ^= 0x01
+    fr[idx % 256 == 77, 13] = 0x01
+    fr[idx % 512 == 130, 24] ^= 0x08   # IPv4 header checksum
+    fr[idx % 1024 == 300, 0:6] = 0xFF  # broadcast destination
+    d_res = torch.zeros(n, dtype=torch.int32, device="cuda")
+    offload.verify_dev(d_out.data_ptr(), obytes, None, ostride, d_olen.data_ptr(), n, rx, d_res.data_ptr(), stream())
+    torch.cuda.synchronize()
+    got = results_to_numpy(d_res)
+    off16 = (np.arange(n, dtype=np.int64) * ostride).astype(np.uint32)
+    exp = oracle_over_device_arena(d_out, off16, np.full(n, 1514, dtype=np.uint32), rx)
+    bad = np.nonzero(got != exp)[0]
+    assert bad.size == 0, (bad[:5], got[bad[:5]], exp[bad[:5]])
+    seen = set(got["verdict"].tolist())
+    assert {Verdict.ACCEPT_UDP, Verdict.ACCEPT_ICMP_ECHO, Verdict.ACCEPT_ICMP_ECHOREPLY, Verdict.DROP_ICMP_TYPE, Verdict.DROP_UDP_CSUM,
+            Verdict.DROP_L2_NOT_FOR_ME, Verdict.DROP_L2_ETHERTYPE, Verdict.DROP_L3_CSUM} <= seen
+
+
 def test_flow_trace_chunks_every_record_against_oracle(offload):
     """The long flow trace, judged the way bench.py's `trace` workload does it (chunks of 16,777,216 records
     generated in HBM at consecutive trace indices), every verdict compared with the CPU oracle and the
