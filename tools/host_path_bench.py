@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the host-pointer entry point unet_verify(): pageable host arena -> pinned
-staging -> H2D -> kernel -> D2H of results.  Printed for DESIGN.md; never the benchmark's `value`."""
+staging -> H2D -> kernel -> D2H of results.  A PCIe-inclusive figure for the record; never the benchmark's `value`."""
 import json
 import os
 import sys

@@ -2,9 +2,10 @@
 only thing that ever crosses GPUs is the per-verdict counter vector (one all-reduce, ~256 bytes).
 
 Two placements are provided:
-  * index ranges  -- rank r owns trace indices [r*n, (r+1)*n): what bench.py uses (weak scaling);
   * flow hash     -- rank = flow_hash5(src, dst, proto, sport, dport) % world, so all frames of a flow
-                     stay on one GPU (for callers that keep per-flow state behind the offload).
+                     stay on one GPU: what bench.py uses for packets (weak scaling: the global batch
+                     grows with the world size);
+  * index ranges  -- rank r owns trace indices [r*n, (r+1)*n): bare headers, which carry no ports.
 The reference has nothing distributed; these helpers only wrap torch.distributed (RCCL on GPUs, gloo in
 the CPU tests).
 """
