@@ -30,6 +30,9 @@ struct Batch {
 // 64..9000-byte mix: 6.1 TB/s against 5.7 TB/s all non-temporal; 1500-byte packets are unaffected).
 // Knob for experiments (bit set = non-temporal): 1 rows 0/1 of a streamed record, 2 lane-parallel
 // records, 4 the loop past 2 KiB.  ld_stream() is always non-temporal (bandwidth yardstick).
+#ifndef UNET_TX_MID_PATH
+#define UNET_TX_MID_PATH 1
+#endif
 #ifndef UNET_TX_SMALL_PATH
 #define UNET_TX_SMALL_PATH 1
 #endif
@@ -781,6 +784,115 @@ __device__ __forceinline__ void tx_build_small(const Batch& pay, u32 my_len, u32
         if (c < nout) tx_store_small(splice<R>(v[c], v[c + 1u]), pout + c);
 }
 
+// Packets of at most 64 chunks (payloads of up to 64 - SH chunks), four at a time, one per 16-lane row of
+// the wave: lane `sub` of a row holds virtual chunks sub, sub+16, sub+32, sub+48 of its row's packet
+// (header chunks from LDS, payload chunks loaded SH chunks further left), the row's payload sum is
+// reduced inside the row, and a chunk's neighbour comes from the next lane of the row -- or, for lane 15,
+// from lane 0's chunk of the next step.  Two groups of four packets are in flight.
+struct TxMidGroup {
+    u32x4 v0, v1, v2, v3;
+    u32 rec, len, flen, oslot, partial;  // per 16-lane row
+    bool udp, row_live;                  // per 16-lane row
+    bool any;                            // wave-uniform
+};
+
+template <u32 SH>
+__device__ __forceinline__ TxMidGroup issue_tx_mid(const Batch& pay, const Tile& t, u32 my_flen, u32 my_oslot, u32 my_partial,
+                                                   bool my_udp, u64& mid) {
+    const u32 sub = t.lane & 15u, q = t.lane >> 4;
+    TxMidGroup g;
+    g.any = mid != 0ull;
+    u32 r[4];
+    bool have[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        have[k] = mid != 0ull;
+        r[k] = have[k] ? (u32)__builtin_ctzll(mid) : 0u;
+        mid &= mid - 1ull;
+    }
+    g.rec = q == 0u ? r[0] : (q == 1u ? r[1] : (q == 2u ? r[2] : r[3]));
+    g.row_live = q == 0u ? have[0] : (q == 1u ? have[1] : (q == 2u ? have[2] : have[3]));
+    g.len = from_lane(t.my_len, g.rec);
+    g.flen = from_lane(my_flen, g.rec);
+    g.oslot = from_lane(my_oslot, g.rec);
+    g.partial = from_lane(my_partial, g.rec);
+    g.udp = from_lane((u32)my_udp, g.rec) != 0u;
+    const u32 slot = from_lane(t.my_slot, g.rec);
+    const u32 nin = g.row_live ? (g.len + 15u) >> 4 : 0u;
+    const u32 last = nin != 0u ? nin - 1u : 0u;
+    const u32x4* p = reinterpret_cast<const u32x4*>(pay.arena + (g.row_live ? (u64)slot * 16u : 0ull));
+    g.v0 = p[min(sub < SH ? 0u : sub - SH, last)];
+    g.v1 = p[min(sub + 16u - SH, last)];
+    g.v2 = p[min(sub + 32u - SH, last)];
+    g.v3 = p[min(sub + 48u - SH, last)];
+    return g;
+}
+
+// Lane i of a 16-lane row receives lane i+1's value; lane 15 receives lane 0's `nxt` (its chunk of the
+// next step).
+__device__ __forceinline__ u32 from_next_in_row(u32 v, u32 nxt) {
+    const int wrap = __builtin_amdgcn_update_dpp(0, (int)nxt, 0x11f, 0xf, 0xf, false);  // row_shr:15: lane 15 <- lane 0
+    return (u32)__builtin_amdgcn_update_dpp(wrap, (int)v, 0x101, 0xf, 0xf, false);     // row_shl:1, lane 15 keeps `wrap`
+}
+
+template <int R, u32 SH>
+__device__ __forceinline__ void consume_tx_mid(const TxMidGroup& g, u32 lane, uint8_t* __restrict__ out_arena,
+                                               const u32x4* __restrict__ park) {
+    const u32 sub = lane & 15u;
+    const u32 nin = g.row_live ? (g.len + 15u) >> 4 : 0u, last = nin != 0u ? nin - 1u : 0u;
+    const u32 nout = g.row_live ? (g.flen + 15u) >> 4 : 0u;
+    const LaneTail lt(g.len);
+    const bool partial = (g.len & 15u) != 0u;
+    // (named values, not an array: conditional updates of array elements end up in scratch memory)
+    u32 acc = 0;
+#define UNET_TXM_MASK(X, I)                                                              \
+    {                                                                                    \
+        const u32 m_ = 16u * (I) + sub, k_ = m_ - SH; /* k_ wraps for the header lanes */ \
+        X = zero_unless(X, m_ >= SH && k_ < nin);                                        \
+        const bool cut_ = partial && k_ == last;                                         \
+        X.x &= cut_ ? lt.m0 : 0xffffffffu;                                               \
+        X.y &= cut_ ? lt.m1 : 0xffffffffu;                                               \
+        X.z &= cut_ ? lt.m2 : 0xffffffffu;                                               \
+        X.w &= cut_ ? lt.m3 : 0xffffffffu;                                               \
+        acc = sum_chunk(X, acc);                                                         \
+    }
+    u32x4 x0 = g.v0, x1 = g.v1, x2 = g.v2, x3 = g.v3;
+    UNET_TXM_MASK(x0, 0u)
+    UNET_TXM_MASK(x1, 1u)
+    UNET_TXM_MASK(x2, 2u)
+    UNET_TXM_MASK(x3, 3u)
+#undef UNET_TXM_MASK
+    acc = dpp_add<0x111, 0xf>(acc);
+    acc = dpp_add<0x112, 0xf>(acc);
+    acc = dpp_add<0x114, 0xf>(acc);
+    acc = dpp_add<0x118, 0xf>(acc);  // lane 15 of the row: the payload's exact sum
+    const u32 total = from_lane(acc, (lane & 48u) | 15u);
+    const u32 ck = bswap16((~fold16(g.partial + bswap16(fold16(total)))) & 0xffffu) << 16;
+    const bool hdr_lane = g.row_live && sub < SH;
+    const u32x4 hv = park[hdr_lane ? g.rec * SH + sub : 0u];
+    x0.x = hdr_lane ? hv.x : x0.x;
+    x0.y = hdr_lane ? hv.y : x0.y;
+    x0.z = hdr_lane ? hv.z : x0.z;
+    x0.w = hdr_lane ? hv.w : x0.w;
+    const bool ck_lane = sub == SH - 1u;
+    x0.w |= ck_lane && g.udp ? ck : 0u;
+    x0.z |= ck_lane && !g.udp ? ck : 0u;
+    u32x4* pout = reinterpret_cast<u32x4*>(out_arena + (u64)g.oslot * 16u);
+#define UNET_TXM_EMIT(X, NX, NY, I)                                                      \
+    {                                                                                    \
+        u32x4 h_ = {0, 0, 0, 0};                                                         \
+        h_.x = from_next_in_row(X.x, NX);                                                \
+        if (R > 4) h_.y = from_next_in_row(X.y, NY);                                     \
+        const u32 m_ = 16u * (I) + sub;                                                  \
+        if (m_ < nout) tx_store_small(splice<R>(X, h_), pout + m_);                      \
+    }
+    UNET_TXM_EMIT(x0, x1.x, x1.y, 0u)
+    UNET_TXM_EMIT(x1, x2.x, x2.y, 1u)
+    UNET_TXM_EMIT(x2, x3.x, x3.y, 2u)
+    UNET_TXM_EMIT(x3, 0u, 0u, 3u)
+#undef UNET_TXM_EMIT
+}
+
 // MODE_L3: packet = 28 header bytes + payload.  MODE_L2: 42 header bytes + payload (+ tap::send's pad).
 // Lane j first prepares packet j's headers (every field and the IPv4 checksum; the L4 checksum as a
 // partial sum) and parks them in LDS; the wave then builds the packets one after another, reading each
@@ -815,8 +927,10 @@ __global__ __launch_bounds__(kBlock) void k_tx_build(Batch pay, const TxDesc* __
     else if ((u64)my_oslot * 16u + (((u64)frame_len + 15u) & ~15ull) > out_bytes) st = UNET_TX_E_RANGE_;
     const bool my_go = t.lane < t.cnt && st == UNET_TX_OK_;
     const bool my_small = UNET_TX_SMALL_PATH && my_go && t.my_len <= 16u * kTxSmallChunks;
+    // payloads of up to 64 - SH chunks: the packet fits the four steps of a 16-lane row
+    const bool my_mid = UNET_TX_MID_PATH && my_go && !my_small && t.my_len <= 16u * (kWave - SH);
 
-    u64 todo = __ballot(my_go && !my_small);
+    u64 todo = __ballot(my_go && !my_small && !my_mid);
     TxRows A, B, C;
 #define UNET_NEXT(X)                                                                 \
     {                                                                                \
@@ -826,7 +940,8 @@ __global__ __launch_bounds__(kBlock) void k_tx_build(Batch pay, const TxDesc* __
         X = issue_rows_shifted<SH>(pay, t.my_len, t.my_slot, t.lane, j, has);        \
     }
     const bool any = todo != 0ull;
-    if (any) {  // the first payloads are on their way while the headers are prepared
+    const u64 mid_mask = __ballot(my_mid);
+    if (any && mid_mask == 0ull) {  // the first payloads are on their way while the headers are prepared
         UNET_NEXT(A)
         UNET_NEXT(B)
     }
@@ -890,6 +1005,25 @@ __global__ __launch_bounds__(kBlock) void k_tx_build(Batch pay, const TxDesc* __
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the parked headers are read by lanes 0..SH-1
     __builtin_amdgcn_wave_barrier();
+
+    // ---- mid-size payloads, four packets at a time (its register buffers are free again afterwards)
+    if (mid_mask != 0ull) {
+        u64 mid = mid_mask;
+        TxMidGroup g0 = issue_tx_mid<SH>(pay, t, frame_len, my_oslot, my_partial, my_udp, mid), g1;
+#pragma nounroll
+        while (true) {
+            g1 = issue_tx_mid<SH>(pay, t, frame_len, my_oslot, my_partial, my_udp, mid);
+            consume_tx_mid<R, SH>(g0, t.lane, out_arena, park);
+            if (!g1.any) break;
+            g0 = issue_tx_mid<SH>(pay, t, frame_len, my_oslot, my_partial, my_udp, mid);
+            consume_tx_mid<R, SH>(g1, t.lane, out_arena, park);
+            if (!g0.any) break;
+        }
+        if (any) {
+            UNET_NEXT(A)
+            UNET_NEXT(B)
+        }
+    }
 
     // ---- short payloads: one packet per lane
     if (my_small)
