@@ -58,9 +58,13 @@ def as_tuples(res: np.ndarray):
 
 
 def random_lengths(rng, n, max_len=9000):
-    """Length mix that hits the kernel's edges: empty, sub-chunk, around 16/1024-byte boundaries, jumbo."""
-    special = np.array([0, 1, 2, 3, 15, 16, 17, 19, 20, 21, 27, 28, 29, 63, 64, 65, 1007, 1008, 1009, 1023, 1024, 1025,
-                        1039, 1040, 1041, 1499, 1500, 1501, 2047, 2048, 2049, 4095, 4096, 4097, 5119, 5120, 5121, 8999, 9000])
+    """Length mix that hits the kernels' edges: empty, sub-chunk, the hand-over points between the per-lane,
+    16-lane-row and whole-wave paths, row and loop-step boundaries of long records, the maximum."""
+    special = np.array([0, 1, 2, 3, 15, 16, 17, 19, 20, 21, 27, 28, 29, 63, 64, 65, 127, 128, 129, 143, 144, 145, 175, 176, 177,
+                        191, 192, 193, 207, 208, 209, 255, 256, 257, 271, 272, 273, 511, 512, 513, 527, 528, 529, 767, 768, 769,
+                        1007, 1008, 1009, 1023, 1024, 1025, 1039, 1040, 1041, 1499, 1500, 1501, 2031, 2032, 2033, 2047, 2048, 2049,
+                        2063, 2064, 2065, 3071, 3072, 3073, 4095, 4096, 4097, 5119, 5120, 5121, 6143, 6144, 6145, 6159, 6160,
+                        6161, 7167, 7168, 7169, 8999, 9000, 10239, 10240, 10241, 65519, 65520, 65521, 65534, 65535])
     special = special[special <= max_len]
     lens = rng.integers(0, max_len + 1, size=n)
     k = min(n, len(special))

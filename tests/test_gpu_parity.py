@@ -169,6 +169,52 @@ def test_csum_batch_random_lengths(offload):
     assert not offload.csum_batch(arena, off16, lens2, s0)[lens2 > 0].any()
 
 
+def test_csum_batch_up_to_maximum_length(offload):
+    rng = np.random.default_rng(13)
+    lens = random_lengths(rng, 2500, max_len=65535)
+    frames = [rng.integers(0, 256, size=int(n), dtype=np.uint8).tobytes() for n in lens]
+    arena, off16, lens2 = unet_amd.pack_arena(frames, pad_byte=0xA7)
+    seeds = rng.integers(0, 65536, size=len(frames)).astype(np.uint16)
+    assert (offload.csum_batch(arena, off16, lens2, seeds) == O.csum_batch(arena, off16, lens2, seeds)).all()
+
+
+@pytest.mark.parametrize("mode", [unet_amd.MODE_L3, unet_amd.MODE_L2])
+def test_verify_well_formed_packets_of_every_edge_length(offload, mode):
+    """Valid UDP / ICMP / TCP packets at every length where the kernel changes its way of reading a record,
+    a third of them damaged in one byte: verdict and checksum value against the oracle."""
+    rng = np.random.default_rng(19 + mode)
+    ifc = unet_amd.Iface("192.0.2.2", "255.255.255.0", mac=bytes.fromhex("02aabbccddee"), mode=mode, ext_tcp=True)
+    lens = [int(x) for x in random_lengths(rng, 400, max_len=65535)[:130] if x >= 40] * 3
+    frames = []
+    for i, total in enumerate(lens):
+        proto = (17, 1, 6)[i % 3]
+        src = int(rng.integers(1, 2**32 - 1))
+        body = rng.integers(0, 256, size=total - 20, dtype=np.uint8).tobytes()
+        if proto == 17:
+            seg = bytearray(struct.pack(">HHHH", 7, 9, total - 20, 0) + body[8:])
+            struct.pack_into(">H", seg, 6, O.udp_send_checksum(src, ifc.unicast, 7, 9, bytes(seg[8:])))
+        elif proto == 1:
+            seg = bytearray(struct.pack(">BBHI", 8, 0, 0, 0x11223344) + body[8:])
+            struct.pack_into(">H", seg, 2, O.icmp_send_checksum(8, 0, 0x11223344, bytes(seg[8:])))
+        else:
+            seg = bytearray(struct.pack(">HHIIBBHHH", 1, 2, 3, 4, 5 << 4, 0x10, 512, 0, 0) + body[20:])
+            pseudo = struct.pack(">IIBBH", src, ifc.unicast, 0, 6, len(seg))
+            struct.pack_into(">H", seg, 16, py_ck(bytes(seg), ~py_ck(pseudo, 0) & 0xFFFF))
+        pkt = bytearray(O.create_ip_header(i & 0xFFFF, proto, src, ifc.unicast, len(seg)) + bytes(seg))
+        if i % 3 == 2 - (i // 3) % 3:
+            pkt[int(rng.integers(0, len(pkt)))] ^= 1 << int(rng.integers(0, 8))
+        frames.append((bytes(ifc.mac) + b"\x02\x00\x00\x00\x00\x09\x08\x00" if mode else b"") + bytes(pkt))
+    frames = [f for f in frames if len(f) <= 65535]
+    arena, off16, lens2 = unet_amd.pack_arena(frames, pad_byte=0x3D)
+    got = offload.verify(arena, off16, lens2, ifc)
+    exp = O.recv_batch(arena, off16, lens2, ifc)
+    bad = np.nonzero(got != exp)[0]
+    assert bad.size == 0, (bad[:5], got[bad[:5]], exp[bad[:5]], lens2[bad[:5]])
+    v = got["verdict"]
+    assert (v == Verdict.ACCEPT_UDP).sum() > 50 and (v == Verdict.ACCEPT_ICMP_ECHO).sum() > 50 and (v == Verdict.ACCEPT_TCP).sum() > 50
+    assert ((v == Verdict.DROP_UDP_CSUM) | (v == Verdict.DROP_TCP_CSUM) | (v == Verdict.DROP_L3_CSUM)).sum() > 30
+
+
 def test_csum_batch_fixed_stride(offload):
     rng = np.random.default_rng(12)
     n, stride16 = 1000, 7

@@ -165,7 +165,11 @@ def _valid_mask(nbytes, ooff, out_len):
 def test_tx_build_matches_oracle(offload, mode):
     rng = np.random.default_rng(17 + mode)
     ifc = unet_amd.Iface("192.0.2.2", "255.255.255.0", mac=bytes.fromhex("02aabbccddee"), mode=mode)
-    lens = LENS * 3 + [int(x) for x in rng.integers(0, 1600, size=6000)] + [65507, 65506, 40000, 9000]
+    # every length around the hand-over points of the kernel's paths (128/129 bytes, 61-62 chunks, the end of
+    # rows 0/1 at 125-126 chunks, the row steps of long payloads), plus a random mix
+    edges = list(range(100, 160)) + list(range(950, 1050)) + list(range(1980, 2080)) + list(range(3000, 3100, 7)) + \
+        [4000, 4079, 4080, 4096, 5000, 6100, 6128, 6129]
+    lens = LENS * 3 + edges + [int(x) for x in rng.integers(0, 1600, size=6000)] + [65507, 65506, 40000, 9000]
     desc, payloads = make_batch(rng, lens, ifc)
     arena, off16, plen = unet_amd.pack_arena(payloads, pad_byte=0x77)
     ooff, obytes = tx_out_layout(plen, mode)
