@@ -9,7 +9,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <new>
+#include <thread>
+#include <vector>
 
 #include "kernels.h"
 #include "pcap.h"
@@ -47,6 +51,75 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+// Helper threads for the copy from the caller's (pageable) memory into the pinned staging buffers: one
+// core moves about 10-15 GB/s, the PCIe link several times that.
+class CopyPool {
+  public:
+    explicit CopyPool(int helpers) {
+        for (int i = 0; i < helpers; i++) th_.emplace_back([this, i] { work(i + 1); });
+    }
+    ~CopyPool() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+            gen_++;
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    void copy(void* dst, const void* src, size_t bytes) {
+        const size_t parts = th_.size() + 1;
+        if (th_.empty() || bytes < (1u << 20)) {
+            memcpy(dst, src, bytes);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> g(m_);
+            dst_ = (char*)dst;
+            src_ = (const char*)src;
+            per_ = ((bytes + parts - 1) / parts + 4095) & ~(size_t)4095;
+            bytes_ = bytes;
+            pending_ = (int)th_.size();
+            gen_++;
+        }
+        cv_.notify_all();
+        slice(0);
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return pending_ == 0; });
+    }
+
+  private:
+    void slice(size_t i) {
+        const size_t lo = i * per_;
+        if (lo < bytes_) memcpy(dst_ + lo, src_ + lo, bytes_ - lo < per_ ? bytes_ - lo : per_);
+    }
+    void work(size_t id) {
+        int seen = 0;
+        while (true) {
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+            }
+            slice(id);
+            {
+                std::lock_guard<std::mutex> g(m_);
+                pending_--;
+            }
+            done_.notify_one();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    char* dst_ = nullptr;
+    const char* src_ = nullptr;
+    size_t per_ = 0, bytes_ = 0;
+    int pending_ = 0, gen_ = 0;
+    bool stop_ = false;
+};
+
 }  // namespace
 
 struct unet_ctx {
@@ -57,6 +130,7 @@ struct unet_ctx {
     hipEvent_t pinned_free[2] = {nullptr, nullptr};
     hipEvent_t copied = nullptr;
     DevBuf d_arena, d_off, d_len, d_out, d_aux, d_tx, d_tx_tab;
+    CopyPool* pool = nullptr;
 };
 
 namespace {
@@ -81,7 +155,7 @@ int h2d(unet_ctx* c, void* dst, const void* src, size_t bytes) {
     while (off < bytes) {
         const size_t nb = bytes - off < kStageBytes ? bytes - off : kStageBytes;
         HIP_TRY(hipEventSynchronize(c->pinned_free[which]));
-        memcpy(c->pinned[which], (const char*)src + off, nb);
+        c->pool->copy(c->pinned[which], (const char*)src + off, nb);
         HIP_TRY(hipMemcpyAsync((char*)dst + off, c->pinned[which], nb, hipMemcpyHostToDevice, c->s_copy));
         HIP_TRY(hipEventRecord(c->pinned_free[which], c->s_copy));
         off += nb;
@@ -202,6 +276,17 @@ int unet_open(int device_id, unet_ctx** out_ctx) {
         unet_close(c);
         return UNET_E_HIP;
     }
+    // staging-copy helpers: UNET_COPY_THREADS counts the calling thread too (default 4, at most 16)
+    int threads = 4;
+    if (const char* t = getenv("UNET_COPY_THREADS")) threads = atoi(t);
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 0 && threads > hw) threads = hw;
+    threads = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
+    c->pool = new (std::nothrow) CopyPool(threads - 1);
+    if (!c->pool) {
+        unet_close(c);
+        return fail(UNET_E_NOMEM, "out of host memory");
+    }
     *out_ctx = c;
     return UNET_OK;
 }
@@ -218,6 +303,7 @@ void unet_close(unet_ctx* c) {
         if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
         if (c->pinned_free[i]) (void)hipEventDestroy(c->pinned_free[i]);
     }
+    delete c->pool;
     if (c->copied) (void)hipEventDestroy(c->copied);
     if (c->s_comp) (void)hipStreamDestroy(c->s_comp);
     if (c->s_copy) (void)hipStreamDestroy(c->s_copy);
