@@ -768,7 +768,7 @@ int unet_stream_read_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint
     if (!ctx || !d_buf || !d_sink) return fail(UNET_E_INVAL, "null argument");
     if (((uintptr_t)d_buf & 15u) != 0) return fail(UNET_E_INVAL, "buffer must be 16-byte aligned");
     HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_stream_read, dim3(4096), dim3(kBlock), 0, pick(ctx, stream), (const u32x4*)d_buf, bytes / 16, d_sink);
+    hipLaunchKernelGGL(k_stream_read, dim3(8192), dim3(kBlock), 0, pick(ctx, stream), (const u32x4*)d_buf, bytes / 16, d_sink);
     HIP_TRY(hipGetLastError());
     return UNET_OK;
 }
