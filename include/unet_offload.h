@@ -246,6 +246,11 @@ int unet_count_verdicts_dev(unet_ctx* ctx, void* stream, const unet_result* d_re
  * (MODE_L2 or MODE_L3 as in iface) and writes one hash per record (0 if the record has
  * no complete IPv4 header). */
 uint32_t unet_flow_hash5(uint32_t src, uint32_t dst, uint8_t proto, uint16_t sport, uint16_t dport);
+/* Host code: the same hash from the bytes of one record (mode as in unet_iface: UNET_MODE_L3 packet or
+ * UNET_MODE_L2 frame).  Ports count for UDP and TCP when the buffer reaches them, else 0; a buffer that
+ * holds no IPv4 header hashes to 0.  Lets a dispatcher place frames on GPUs before any GPU has seen them;
+ * equals unet_flow_hash_dev's result for the same bytes. */
+uint32_t unet_flow_hash_record(const uint8_t* rec, size_t len, int mode);
 int unet_flow_hash_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_t arena_bytes,
                        const uint32_t* d_off16, uint32_t stride16, const uint32_t* d_len, uint32_t n,
                        const unet_iface* iface, uint32_t* d_hash);

@@ -233,12 +233,58 @@ static void gpu_send_tests() {
     }
 }
 
+// Three contexts on one GPU stand in for three GPUs: flow-hash placement, per-shard threads, merged verdicts.
+static void gpu_sharded_tests() {
+    const uint32_t n = 6000;
+    unet_iface ifc{};
+    ifc.unicast = 0xC0000202;
+    ifc.broadcast = 0xC00002FF;
+    ifc.ext_tcp = 1;
+    std::vector<uint32_t> off(n), len(n);
+    uint64_t bytes = 0;
+    CHECK(unet_synth_layout(UNET_SYNTH_FLOWS, 0x756e6574ull, 4242, n, off.data(), len.data(), &bytes) == UNET_OK);
+    std::vector<uint8_t> arena(bytes + 64);
+    uint8_t* base = arena.data() + ((16 - (reinterpret_cast<uintptr_t>(arena.data()) & 15)) & 15);
+    CHECK(unet_synth_host(UNET_SYNTH_FLOWS, 0x756e6574ull, 4242, n, &ifc, off.data(), len.data(), base, bytes) == UNET_OK);
+    std::vector<std::vector<uint8_t>> frames(n);
+    for (uint32_t i = 0; i < n; i++) frames[i].assign(base + size_t(off[i]) * 16, base + size_t(off[i]) * 16 + len[i]);
+
+    ShardedOffload many({0, 0, 0});
+    const ShardedOffload::Report rep = many.verify(frames, ifc);
+    Offload one(0);
+    FrameArena a;
+    for (auto& f : frames) a.push(f.data(), f.size());
+    const std::vector<unet_result> ref = one.verify(a, ifc);
+    oracle_iface oi{};
+    std::memcpy(&oi, &ifc, sizeof oi);
+    size_t sizes[3] = {0, 0, 0};
+    bool same = true, placed = true;
+    for (uint32_t i = 0; i < n; i++) {
+        same &= std::memcmp(&rep.results[i], &ref[i], sizeof(unet_result)) == 0;
+        const oracle_result o = oracle_ipv4_recv(frames[i].data(), frames[i].size(), &oi);
+        same &= o.verdict == rep.results[i].verdict && o.csum == rep.results[i].csum;
+        placed &= rep.shard[i] == oracle_flow_hash_record(frames[i].data(), frames[i].size(), &oi) % 3;
+        sizes[rep.shard[i]]++;
+    }
+    CHECK(same);
+    CHECK(placed);
+    CHECK(rep.shard_sizes[0] == sizes[0] && rep.shard_sizes[1] == sizes[1] && rep.shard_sizes[2] == sizes[2]);
+    CHECK(sizes[0] > n / 6 && sizes[1] > n / 6 && sizes[2] > n / 6);
+    // frames of one flow always meet on the same shard, and the L2 form of a frame hashes like its L3 form
+    std::vector<uint8_t> l2(14 + frames[7].size());
+    l2[12] = 0x08;
+    std::memcpy(l2.data() + 14, frames[7].data(), frames[7].size());
+    CHECK(unet_flow_hash_record(l2.data(), l2.size(), UNET_MODE_L2) == unet_flow_hash_record(frames[7].data(), frames[7].size(), UNET_MODE_L3));
+    CHECK(unet_flow_hash_record(l2.data(), 13, UNET_MODE_L2) == 0 && unet_flow_hash_record(frames[7].data(), 19, UNET_MODE_L3) == 0);
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "--cpu";
     cpu_tests();
     if (mode == "--gpu") {
         gpu_tests();
         gpu_send_tests();
+        gpu_sharded_tests();
     }
     if (g_fail) {
         std::printf("%d check(s) failed\n", g_fail);

@@ -147,3 +147,21 @@ def test_flow_trace_tuples_match_the_bytes_and_are_skewed():
     assert len(ids) < 57600 and counts[0] >= 4
     res = O.recv_batch(*unet_amd.synth_host(unet_amd.SYNTH_FLOWS, SEED, 0, 4096, ifc), ifc)
     assert {20, 24, 15, 16} & set(res["verdict"].tolist())
+
+
+def test_flow_hash_record_on_the_host_matches_the_oracle():
+    """unet_flow_hash_record (what a multi-GPU dispatcher calls before any GPU has seen the frame) against the
+    oracle's rule, L3 and L2 forms, including buffers too short to reach the ports or the header."""
+    from unet_amd import _ffi as F
+    ifc = unet_amd.Iface(ext_tcp=True)
+    arena, off16, lens = unet_amd.synth_host(unet_amd.SYNTH_IMIX, SEED, 77, 3000, ifc)
+    l2 = ifc.replace(mode=1)
+    for r in range(3000):
+        rec = arena[int(off16[r]) * 16:int(off16[r]) * 16 + int(lens[r])].tobytes()
+        assert F.flow_hash_record(rec, 0) == O.flow_hash_record(rec, ifc)
+        if r % 5 == 0:
+            frame = b"\x02" * 12 + (b"\x08\x00" if r % 10 else b"\x08\x06") + rec
+            assert F.flow_hash_record(frame, 1) == O.flow_hash_record(frame, l2)
+            for cut in (0, 13, 14, 33, 34, 37, 38):
+                assert F.flow_hash_record(frame[:cut], 1) == O.flow_hash_record(frame[:cut], l2)
+                assert F.flow_hash_record(rec[:cut], 0) == O.flow_hash_record(rec[:cut], ifc)

@@ -152,6 +152,7 @@ _SIGS = {
                                 _u32p, _u32p, _u8p]),
     "unet_count_verdicts_dev": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _u64p]),
     "unet_flow_hash5": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint16, C.c_uint16]),
+    "unet_flow_hash_record": (C.c_uint32, [C.c_char_p, C.c_size_t, C.c_int]),
     "unet_flow_hash_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _u32p]),
     "unet_synth_len": (C.c_uint32, [C.c_int, C.c_uint64, C.c_uint64]),
     "unet_synth_layout": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, _u32p, _u32p, C.POINTER(C.c_uint64)]),
@@ -303,6 +304,12 @@ def pcap_write(arena: np.ndarray, off16, lens: np.ndarray, linktype: int = LINKT
     _check(lib.unet_pcap_write(_np_ptr(arena), arena.nbytes, _np_ptr(off16), stride16, _np_ptr(lens), len(lens), linktype,
                                _np_ptr(out), out.nbytes, C.byref(need)))
     return out.tobytes()
+
+
+def flow_hash_record(rec: bytes, mode: int = 0) -> int:
+    """Flow hash of one packet (mode 0) or Ethernet frame (mode 1) from its bytes, on the host."""
+    rec = bytes(rec)
+    return int(load_library().unet_flow_hash_record(rec, len(rec), mode))
 
 
 def flow_hash5(src: int, dst: int, proto: int, sport: int, dport: int) -> int:

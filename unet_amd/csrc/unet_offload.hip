@@ -618,6 +618,26 @@ uint32_t unet_flow_hash5(uint32_t src, uint32_t dst, uint8_t proto, uint16_t spo
     return flow_hash5(src, dst, proto, sport, dport);
 }
 
+uint32_t unet_flow_hash_record(const uint8_t* rec, size_t len, int mode) {
+    if (!rec) return 0;
+    if (mode == UNET_MODE_L2) {
+        if (len < 14 || rec[12] != 0x08 || rec[13] != 0x00) return 0;
+        rec += 14;
+        len -= 14;
+    }
+    if (len < 20) return 0;
+    auto be16 = [](const uint8_t* p) { return (u32)((p[0] << 8) | p[1]); };
+    auto be32 = [](const uint8_t* p) { return ((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | p[3]; };
+    const u32 proto = rec[9];
+    const size_t hl = (size_t)(rec[0] & 0x0f) * 4;
+    u32 sport = 0, dport = 0;
+    if ((proto == 17 || proto == 6) && hl >= 20 && hl + 4 <= len) {
+        sport = be16(rec + hl);
+        dport = be16(rec + hl + 2);
+    }
+    return flow_hash5(be32(rec + 12), be32(rec + 16), proto, sport, dport);
+}
+
 int unet_flow_hash_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_t arena_bytes,
                        const uint32_t* d_off16, uint32_t stride16, const uint32_t* d_len, uint32_t n,
                        const unet_iface* iface, uint32_t* d_hash) {

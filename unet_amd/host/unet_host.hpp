@@ -25,6 +25,7 @@
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/unet_offload.h"
@@ -177,6 +178,68 @@ class Offload {
 
   private:
     unet_ctx* ctx_ = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Several GPUs behind one call.  Frames are independent, so each goes to the GPU chosen by the hash of its
+// flow 5-tuple (all frames of a flow meet on one GPU; nothing is exchanged between GPUs); every GPU gets its
+// own arena and is driven by its own host thread, and the verdicts come back in the caller's order.
+class ShardedOffload {
+  public:
+    // One context per entry; a device id may appear more than once (several contexts on one GPU).
+    explicit ShardedOffload(const std::vector<int>& devices) {
+        if (devices.empty()) throw std::invalid_argument("need at least one device");
+        for (int d : devices) gpus_.push_back(std::make_unique<Offload>(d));
+        arenas_.resize(gpus_.size());
+        for (auto& a : arenas_) a = std::make_unique<FrameArena>();
+    }
+    size_t shards() const { return gpus_.size(); }
+    static uint32_t shard_of(const uint8_t* frame, size_t len, int mode, size_t nshards) {
+        return static_cast<uint32_t>(unet_flow_hash_record(frame, len, mode) % nshards);
+    }
+
+    struct Report {
+        std::vector<unet_result> results;   // input order
+        std::vector<uint32_t> shard;        // input order: which GPU judged the frame
+        std::vector<size_t> shard_sizes;
+    };
+    Report verify(const std::vector<std::vector<uint8_t>>& frames, const unet_iface& iface) {
+        const size_t n = frames.size(), g = gpus_.size();
+        Report rep;
+        rep.results.resize(n);
+        rep.shard.resize(n);
+        rep.shard_sizes.assign(g, 0);
+        std::vector<std::vector<size_t>> index(g);
+        for (auto& a : arenas_) a->clear();
+        for (size_t i = 0; i < n; i++) {
+            const uint32_t s = shard_of(frames[i].data(), frames[i].size(), iface.mode, g);
+            rep.shard[i] = s;
+            arenas_[s]->push(frames[i].data(), frames[i].size());
+            index[s].push_back(i);
+        }
+        std::vector<std::vector<unet_result>> part(g);
+        std::vector<std::string> err(g);
+        std::vector<std::thread> th;
+        for (size_t s = 0; s < g; s++)
+            th.emplace_back([&, s] {
+                try {
+                    part[s] = gpus_[s]->verify(*arenas_[s], iface);
+                } catch (const std::exception& e) {
+                    err[s] = e.what();
+                }
+            });
+        for (auto& t : th) t.join();
+        for (size_t s = 0; s < g; s++) {
+            if (!err[s].empty()) throw std::runtime_error("shard " + std::to_string(s) + ": " + err[s]);
+            rep.shard_sizes[s] = index[s].size();
+            for (size_t k = 0; k < index[s].size(); k++) rep.results[index[s][k]] = part[s][k];
+        }
+        return rep;
+    }
+
+  private:
+    std::vector<std::unique_ptr<Offload>> gpus_;
+    std::vector<std::unique_ptr<FrameArena>> arenas_;
 };
 
 // ---------------------------------------------------------------------------------------------
