@@ -51,24 +51,30 @@ __device__ __forceinline__ u32x4 ld_far(const u32x4* p) { return (UNET_NT_MASK &
 // Tile machinery shared by k_verify, k_csum and k_generate.
 //
 // One wave owns TILE consecutive records; lane j keeps record j's length, slot and, at the end, its
-// exact byte-swapped-word sum over [0, len).  Work split inside the wave:
-//   * streaming, wave-cooperative, one record at a time (records longer than kSmallChunks chunks):
-//     all 64 lanes load the record in 16-byte chunks, sum the FULL chunks, and a DPP reduction leaves
-//     the sum in lane j.  Nothing here depends on the record's contents.  The first six chunks (every
-//     header byte any check can look at) and the partial last chunk are parked in LDS.
-//   * lane-parallel: records of at most kSmallChunks chunks are loaded and summed by their own lane;
-//     afterwards every lane adds the byte-masked tail chunk of its streamed record.
+// exact byte-swapped-word sum over [0, len).  Work split inside the wave, by record length:
+//   * longer than 1 KiB -- streaming, wave-cooperative, one record at a time: all 64 lanes load the
+//     record in 16-byte chunks, sum the FULL chunks, and a DPP reduction leaves the sum in lane j;
+//   * up to 1 KiB -- the same with groups of 4, 8 or 16 lanes per record, 16, 8 or 4 records at a time;
+//   * at most kSmallChunks chunks -- lane-parallel: loaded and summed by the record's own lane.
+//   Nothing in the first two depends on the record's contents; the first six chunks (every header byte
+//   any check can look at) and the partial last chunk are parked in LDS, and afterwards every lane adds
+//   the byte-masked tail chunk of its own record.
 // Callers then run their O(1)-per-record logic lane-parallel on headers read back from LDS, i.e. once
 // per tile on the vector unit instead of once per record on the (per-CU, shared) scalar unit.
 #ifndef UNET_SMALL_CHUNKS
-#define UNET_SMALL_CHUNKS 12  // measured break-even with the 16-lane-row path: 192 bytes
+#define UNET_SMALL_CHUNKS 5   // above 80 bytes a record is read by a group of 4, 8 or 16 lanes (measured break-even)
+#endif
+#ifndef UNET_ROW4_CHUNKS
+#define UNET_ROW4_CHUNKS 16
 #endif
 constexpr u32 kSmallChunks = UNET_SMALL_CHUNKS;  // records of up to this many chunks are handled by a single lane
 constexpr u32 kHdrChunks = 6;     // 96 bytes: 14 (Ethernet) + 60 (max IPv4 header) + 16 (deepest L4 field) = 90
 // + the record's partial last chunk.  7 chunks = 28 dwords: lanes writing the same chunk of their own
 // records spread over the LDS banks (a power-of-two stride would put them all on the same few).
 constexpr u32 kLdsChunksPerRec = kHdrChunks + 1;
-constexpr u32 kMidChunks = 64;    // longer records up to 64 chunks (1024 bytes) are handled by a 16-lane row
+constexpr u32 kRow4Chunks = UNET_ROW4_CHUNKS;  // longer records up to 16 chunks (256 bytes) are handled by 4 lanes,
+constexpr u32 kRow8Chunks = 32;   // up to 32 chunks (512 bytes) by 8 lanes,
+constexpr u32 kMidChunks = 64;    // up to 64 chunks (1024 bytes) by a 16-lane row
 
 // Header dwords of a lane's own record, parked in LDS.
 struct LdsFetch {
@@ -242,79 +248,93 @@ __device__ __forceinline__ u32 from_lane(u32 v, u32 src_lane) {
     return (u32)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
 }
 
-// Records of kSmallChunks+1..64 chunks: four at a time, one per 16-lane row of the wave (a whole wave on one such
-// record would leave most lanes idle).  Every lane issues exactly four loads -- chunks sub, sub+16,
-// sub+32, sub+48 of its row's record, clamped to the last chunk -- with the default cache policy (each
-// holds or neighbours a record end).  Two groups of four are in flight: the next group's loads go out
-// before the current one is summed.  A row's sum of full chunks is reduced with four row_shr steps and
-// left in `sums[record]`; the first six chunks and the cut chunk go to the record's LDS area.
-struct MidGroup {
+// Mid-size records, 64/W at a time, W (8 or 16) neighbouring lanes per record -- a whole wave on one such
+// record would leave most lanes idle and keep little in flight.  Lane `sub` of a group loads chunks sub,
+// sub+W, sub+2W, sub+3W of its group's record (exactly four loads, clamped to the last chunk, default
+// cache policy: each holds or neighbours a record end), so W = 8 serves records of up to 32 chunks with one
+// full 128-byte line per record and load, W = 16 records of up to 64 chunks.  Two steps are in flight: the
+// next step's loads go out before the current one is summed.  The sum of a record's full chunks is reduced
+// inside its group with DPP butterflies and left in `sums[record]`; the first six chunks and the cut chunk
+// go to the record's LDS area.  `list` holds the tile's records of this class, in lane order.
+struct RowStep {
     u32x4 v0, v1, v2, v3;
-    u32 rec, len;   // per 16-lane row
-    bool row_live;  // per 16-lane row
-    bool any;       // wave-uniform: the group holds at least one record
+    u32 rec, len;    // per group
+    bool row_live;   // per group
 };
 
-__device__ __forceinline__ MidGroup issue_mid(const Batch& b, const Tile& t, u64& mid) {
-    const u32 sub = t.lane & 15u, q = t.lane >> 4;
-    MidGroup g;
-    g.any = mid != 0ull;
-    u32 r[4];
-    bool have[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        have[k] = mid != 0ull;
-        r[k] = have[k] ? (u32)__builtin_ctzll(mid) : 0u;
-        mid &= mid - 1ull;  // stays 0 once empty
-    }
-    g.rec = q == 0u ? r[0] : (q == 1u ? r[1] : (q == 2u ? r[2] : r[3]));
-    g.row_live = q == 0u ? have[0] : (q == 1u ? have[1] : (q == 2u ? have[2] : have[3]));
+template <u32 W>
+__device__ __forceinline__ RowStep issue_rows_step(const Batch& b, const Tile& t, const u32* __restrict__ list, u32 first, u32 count) {
+    const u32 sub = t.lane & (W - 1u), k = first + t.lane / W;
+    RowStep g;
+    g.row_live = k < count;
+    g.rec = list[g.row_live ? k : 0u];
     g.len = from_lane(t.my_len, g.rec);
     const u32 slot = from_lane(t.my_slot, g.rec);
     const u32 nch = g.row_live ? (g.len + 15u) >> 4 : 0u;
     const u32 last = nch != 0u ? nch - 1u : 0u;
     const u32x4* p = reinterpret_cast<const u32x4*>(b.arena + (g.row_live ? (u64)slot * 16u : 0ull));
     g.v0 = p[min(sub, last)];
-    g.v1 = p[min(sub + 16u, last)];
-    g.v2 = p[min(sub + 32u, last)];
-    g.v3 = p[min(sub + 48u, last)];
+    g.v1 = p[min(sub + W, last)];
+    g.v2 = p[min(sub + 2u * W, last)];
+    g.v3 = p[min(sub + 3u * W, last)];
     return g;
 }
 
-template <bool PARK_HDR>
-__device__ __forceinline__ void consume_mid(const MidGroup& g, u32 lane, u32x4* __restrict__ park, u32* __restrict__ sums) {
-    const u32 sub = lane & 15u;
+// Sum over each group of W neighbouring lanes, left in every lane of the group.
+template <u32 W>
+__device__ __forceinline__ u32 group_sum(u32 v) {
+    v = dpp_add<0xb1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4e, 0xf>(v);   // quad_perm [2,3,0,1]
+    if (W >= 8u) v = dpp_add<0x141, 0xf>(v);   // row_half_mirror: the other quad of the 8
+    if (W == 16u) v = dpp_add<0x140, 0xf>(v);  // row_mirror: the other 8 of the 16
+    return v;
+}
+
+template <u32 W, bool PARK_HDR>
+__device__ __forceinline__ void consume_rows_step(const RowStep& g, u32 lane, u32x4* __restrict__ park, u32* __restrict__ sums) {
+    const u32 sub = lane & (W - 1u);
     const u32 nfull = g.row_live ? g.len >> 4 : 0u;
     u32x4* mine = park + g.rec * kLdsChunksPerRec;
-    if (PARK_HDR && g.row_live && sub < kHdrChunks) mine[sub] = g.v0;
-    if (g.row_live && (g.len & 15u) != 0u && sub == (nfull & 15u)) {
-        const u32 w = nfull >> 4;  // which of the four loads holds the cut chunk
+    if (PARK_HDR && g.row_live) {  // chunks 0..5: in v0 for W >= 8, in v0 and v1 for W = 4
+        if (sub < kHdrChunks) mine[sub] = g.v0;
+        if (W < kHdrChunks && sub + W < kHdrChunks) mine[sub + W] = g.v1;
+    }
+    if (g.row_live && (g.len & 15u) != 0u && sub == (nfull & (W - 1u))) {
+        const u32 w = nfull / W;  // which of the four loads holds the cut chunk
         mine[kHdrChunks] = w == 0u ? g.v0 : (w == 1u ? g.v1 : (w == 2u ? g.v2 : g.v3));
     }
     u32 acc = sum_chunk(zero_unless(g.v0, sub < nfull), 0u);
-    acc = sum_chunk(zero_unless(g.v1, sub + 16u < nfull), acc);
-    acc = sum_chunk(zero_unless(g.v2, sub + 32u < nfull), acc);
-    acc = sum_chunk(zero_unless(g.v3, sub + 48u < nfull), acc);
-    acc = dpp_add<0x111, 0xf>(acc);  // row_shr:1
-    acc = dpp_add<0x112, 0xf>(acc);  // row_shr:2
-    acc = dpp_add<0x114, 0xf>(acc);  // row_shr:4
-    acc = dpp_add<0x118, 0xf>(acc);  // row_shr:8 -> lane 15 of the row holds the row's sum
-    if (g.row_live && sub == 15u) sums[g.rec] = acc;
+    acc = sum_chunk(zero_unless(g.v1, sub + W < nfull), acc);
+    acc = sum_chunk(zero_unless(g.v2, sub + 2u * W < nfull), acc);
+    acc = sum_chunk(zero_unless(g.v3, sub + 3u * W < nfull), acc);
+    acc = group_sum<W>(acc);
+    if (g.row_live && sub == 0u) sums[g.rec] = acc;
 }
 
-template <bool PARK_HDR>
-__device__ __forceinline__ void mid_records(const Batch& b, const Tile& t, u64 mid, u32x4* __restrict__ park,
-                                            u32* __restrict__ sums) {
-    if (mid == 0ull) return;
-    MidGroup g0 = issue_mid(b, t, mid), g1;
+template <u32 W, bool PARK_HDR>
+__device__ __forceinline__ void rows_path(const Batch& b, const Tile& t, bool mine_here, u32* __restrict__ list,
+                                          u32x4* __restrict__ park, u32* __restrict__ sums) {
+    constexpr u32 kPerStep = kWave / W;
+    const u64 mask = __ballot(mine_here);
+    if (mask == 0ull) return;
+    const u32 count = (u32)__builtin_popcountll(mask);
+    // the records of this class, compacted in lane order
+    if (mine_here) list[__builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u))] = t.lane;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    u32 next = 0;
+    RowStep g0 = issue_rows_step<W>(b, t, list, next, count), g1;
+    next += kPerStep;
 #pragma nounroll
     while (true) {
-        g1 = issue_mid(b, t, mid);
-        consume_mid<PARK_HDR>(g0, t.lane, park, sums);
-        if (!g1.any) break;
-        g0 = issue_mid(b, t, mid);
-        consume_mid<PARK_HDR>(g1, t.lane, park, sums);
-        if (!g0.any) break;
+        g1 = issue_rows_step<W>(b, t, list, next, count);
+        consume_rows_step<W, PARK_HDR>(g0, t.lane, park, sums);
+        if (next >= count) break;
+        next += kPerStep;
+        g0 = issue_rows_step<W>(b, t, list, next, count);
+        consume_rows_step<W, PARK_HDR>(g1, t.lane, park, sums);
+        if (next >= count) break;
+        next += kPerStep;
     }
 }
 
@@ -327,6 +347,8 @@ __device__ __forceinline__ u32 tile_sums(const Batch& b, const Tile& t, u32x4* _
     const u32 my_nch = t.my_ok ? (t.my_len + 15u) >> 4 : 0u;
     const bool my_small = t.my_ok && my_nch >= 1u && my_nch <= kSmallChunks;
     const bool my_mid = UNET_MID_PATH && t.my_ok && my_nch > kSmallChunks && my_nch <= kMidChunks;
+    const bool my_row4 = my_mid && my_nch <= kRow4Chunks;
+    const bool my_row8 = my_mid && !my_row4 && my_nch <= kRow8Chunks;
     const bool my_big = t.my_ok && my_nch > kSmallChunks && !my_mid;
     const LaneTail tail(t.my_len);
     const bool my_partial = (t.my_len & 15u) != 0u;
@@ -334,7 +356,12 @@ __device__ __forceinline__ u32 tile_sums(const Batch& b, const Tile& t, u32x4* _
 
     // ---- mid-size records (up to 1 KiB), four at a time (its register buffers are free again afterwards)
     u32* sums = reinterpret_cast<u32*>(park + TILE * kLdsChunksPerRec);  // one u32 per record of the tile
-    if (UNET_MID_PATH) mid_records<PARK_HDR>(b, t, __ballot(my_mid), park, sums);
+    u32* list = sums + TILE;                                              // and one list entry
+    if (UNET_MID_PATH) {
+        if (kRow4Chunks > kSmallChunks) rows_path<4, PARK_HDR>(b, t, my_row4, list, park, sums);
+        rows_path<8, PARK_HDR>(b, t, my_row8, list, park, sums);
+        rows_path<16, PARK_HDR>(b, t, my_mid && !my_row4 && !my_row8, list, park, sums);
+    }
 
     // ---- streamed records: their first loads go out before the lane-parallel part
     u64 todo = __ballot(my_big);
@@ -449,9 +476,9 @@ __device__ __forceinline__ u32 tile_sums(const Batch& b, const Tile& t, u32x4* _
     return my_total;
 }
 
-// Per wave: TILE record areas of kLdsChunksPerRec chunks, then TILE u32 sums (TILE/4 chunks, at least one).
+// Per wave: TILE record areas of kLdsChunksPerRec chunks, then TILE u32 sums and TILE u32 list entries.
 #define UNET_TILE_LDS(TILE)                                                                         \
-    constexpr u32 kWaveLds = (TILE) * kLdsChunksPerRec + ((TILE) + 3u) / 4u;                        \
+    constexpr u32 kWaveLds = (TILE) * kLdsChunksPerRec + (2u * (TILE) + 3u) / 4u;                   \
     __shared__ u32x4 lds[(kBlock / kWave) * kWaveLds];                                              \
     u32x4* park = lds + (threadIdx.x >> 6) * kWaveLds
 
