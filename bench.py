@@ -47,6 +47,7 @@ WORKLOADS = {
     "generate": (unet_amd.SYNTH_UDP1500, 1 << 22, 94),
     "txbuild": (unet_amd.SYNTH_UDP1500, 1 << 22, 94),
     "eth1514": (unet_amd.SYNTH_UDP1500, 1 << 22, 94),
+    "tximix": (unet_amd.SYNTH_IMIX, 1 << 23, 0),
 }
 DESCRIPTION = {
     "udp1500": "4,194,304 x 1500-byte IPv4/UDP packets per GPU (BASELINE configs[2])",
@@ -56,6 +57,7 @@ DESCRIPTION = {
     "csum": "calculate_checksum over 4,194,304 x 1500-byte records per GPU (unet_csum_batch_dev)",
     "generate": "transmit-side checksum fill of 4,194,304 x 1500-byte IPv4/UDP packets per GPU, in place (unet_generate_dev)",
     "txbuild": "4,194,304 x 1500-byte IPv4/UDP packets per GPU built from 1472-byte payloads + descriptors (unet_tx_build_dev)",
+    "tximix": "8,388,608 IPv4/UDP packets per GPU built from payloads of IMIX sizes (36-8972 bytes) + descriptors (unet_tx_build_dev)",
     "eth1514": "4,194,304 x 1514-byte Ethernet frames per GPU (IPv4/UDP inside, built by unet_tx_build_dev in L2 mode, faults injected), judged in L2 mode",
 }
 
@@ -146,6 +148,29 @@ class Batch:
             self.alg_bytes -= 2 * self.n      # 2-byte results
         elif op == "generate":
             self.alg_bytes += self.n          # 4 bytes of checksum fields + 1 status byte instead of a 4-byte result
+        elif op == "tximix":
+            # the resident IMIX records serve as payloads: a record of L bytes gives an L-28-byte payload, so the
+            # built packets have the IMIX sizes again
+            from unet_amd._ffi import TX_DESC_DTYPE
+            self.rx = unet_amd.Iface("198.51.100.7", "255.255.255.0")
+            self.tx_ifc = ifc.replace(mode=0)
+            desc = np.zeros(self.n, dtype=TX_DESC_DTYPE)
+            rng = np.random.default_rng(SEED + first_idx)
+            desc["src"], desc["dst"], desc["proto"] = ifc.unicast, self.rx.unicast, 17
+            desc["l4a"] = rng.integers(0, 65536, size=self.n)
+            desc["l4b"] = rng.integers(0, 65536, size=self.n)
+            desc["ip_id"] = np.arange(self.n) & 0xFFFF
+            self.desc = torch.from_numpy(desc.view(np.uint8).reshape(-1)).cuda()
+            self.plen = torch.clamp(self.len - 28, min=0)
+            oslots = (self.plen.to(torch.int64) + 28 + 15) // 16
+            self.ooff = (torch.cumsum(oslots, 0) - oslots).to(torch.int32)
+            self.out_bytes = int(oslots.sum().item()) * 16
+            self.out_arena = torch.zeros(self.out_bytes + 16, dtype=torch.uint8, device="cuda")
+            self.olen = torch.zeros(self.n, dtype=torch.int32, device="cuda")
+            self.status = torch.zeros(self.n, dtype=torch.uint8, device="cuda")
+            psum = int(self.plen.to(torch.int64).sum().item())
+            # payload + packet + descriptor + payload offset and length, output offset, output length, status
+            self.alg_bytes = psum + (psum + 28 * self.n) + self.n * (28 + 4 + 4 + 4 + 4 + 1)
         elif op in ("txbuild", "eth1514"):
             # the resident records serve as 1472-byte payloads; every packet goes to one receiver address
             from unet_amd._ffi import TX_DESC_DTYPE
@@ -189,7 +214,7 @@ class Batch:
             off_ptr = None if self.stride16 else self.off.data_ptr()
             self.ctx.generate_dev(self.arena.data_ptr(), self.nbytes, off_ptr, self.stride16, self.len.data_ptr(), self.n,
                                   self.out.data_ptr(), self.stream)
-        elif self.op == "txbuild":
+        elif self.op in ("txbuild", "tximix"):
             self.build()
         elif self.op == "eth1514":
             self.ctx.verify_dev(self.out_arena.data_ptr(), self.out_bytes, None, self.ostride, self.olen.data_ptr(), self.n, self.rx,
@@ -202,6 +227,11 @@ class Batch:
                                 self.ifc, self.out.data_ptr(), self.stream)
 
     def build(self):
+        if self.op == "tximix":
+            self.ctx.tx_build_dev(self.arena.data_ptr(), self.nbytes, self.off.data_ptr(), 0, self.plen.data_ptr(), self.desc.data_ptr(),
+                                  self.n, self.tx_ifc, self.out_arena.data_ptr(), self.out_bytes, self.ooff.data_ptr(),
+                                  self.olen.data_ptr(), self.status.data_ptr(), self.stream)
+            return
         self.ctx.tx_build_dev(self.arena.data_ptr(), self.nbytes, None, 94, self.plen.data_ptr(), self.desc.data_ptr(), self.n,
                               self.tx_ifc, self.out_arena.data_ptr(), self.out_bytes, self.ooff.data_ptr(), self.olen.data_ptr(),
                               self.status.data_ptr(), self.stream)
@@ -337,10 +367,10 @@ def main():
     # rotated over several distinct batches (consecutive index ranges of the same trace) so that no
     # launch finds its input in cache.
     rotate = args.rotate if args.rotate else (6 if kind == unet_amd.SYNTH_IPV4_HDR20 else 1)
-    op = args.workload if args.workload in ("csum", "generate", "txbuild", "eth1514") else "verify"
+    op = args.workload if args.workload in ("csum", "generate", "txbuild", "eth1514", "tximix") else "verify"
     batches = [Batch(ctx, stream, kind, ifc, r * n_global, n_global, shard_world, shard_rank, stride16, op) for r in range(rotate)]
     b0 = batches[0]
-    kernel = {"csum": "k_csum", "generate": "k_generate", "txbuild": "k_tx_build<MODE_L3>", "eth1514": "k_verify<MODE_L2>"}.get(op, "k_ipv4_validate_rows" if kind == unet_amd.SYNTH_IPV4_HDR20 else "k_verify<MODE_L3>")
+    kernel = {"csum": "k_csum", "generate": "k_generate", "txbuild": "k_tx_build<MODE_L3>", "tximix": "k_tx_build<MODE_L3>", "eth1514": "k_verify<MODE_L2>"}.get(op, "k_ipv4_validate_rows" if kind == unet_amd.SYNTH_IPV4_HDR20 else "k_verify<MODE_L3>")
     torch.cuda.synchronize()
 
     # ---- timed region
@@ -365,6 +395,8 @@ def main():
     if op == "txbuild":
         # judge the built packets as the receiver would: every one must be accepted
         ctx.verify_dev(b0.out_arena.data_ptr(), b0.out_bytes, None, b0.ostride, b0.olen.data_ptr(), b0.n, b0.rx, b0.out.data_ptr(), stream)
+    if op == "tximix":
+        ctx.verify_dev(b0.out_arena.data_ptr(), b0.out_bytes, b0.ooff.data_ptr(), 0, b0.olen.data_ptr(), b0.n, b0.rx, b0.out.data_ptr(), stream)
     if op == "csum":
         b0.out.zero_()  # 16-bit checksums are not verdicts: nothing to count
     d_cnt = b0.counts()
@@ -389,6 +421,9 @@ def main():
         local_cnt = d_cnt.cpu().numpy().copy()
         cnt = shard.allreduce_counts(d_cnt, dist).cpu().numpy()
         parity = bool(local_cnt[Verdict.ACCEPT_UDP] + local_cnt[Verdict.DROP_UDP_LEN] == b0.n)
+    if op == "tximix":
+        parity = bool(local_cnt[Verdict.ACCEPT_UDP] == b0.n and int(b0.status.max().item()) == 0
+                      and bool((b0.olen == b0.plen + 28).all().item()))
     if op == "txbuild":
         parity = bool(local_cnt[Verdict.ACCEPT_UDP] == b0.n and int(b0.status.max().item()) == 0
                       and int(b0.olen.min().item()) == 1500 == int(b0.olen.max().item()))
@@ -423,24 +458,25 @@ def main():
     torch.cuda.synchronize()
     stream_gbps = b0.nbytes * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
     copy_gbps = None
-    if op == "txbuild":
+    if op in ("txbuild", "tximix"):
         # read+write yardstick: a plain device-to-device copy of the payload arena into the packet arena
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        b0.out_arena[:b0.nbytes].copy_(b0.arena[:b0.nbytes])
+        cb = min(b0.nbytes, b0.out_bytes)
+        b0.out_arena[:cb].copy_(b0.arena[:cb])
         e0.record()
         for _ in range(5):
-            b0.out_arena[:b0.nbytes].copy_(b0.arena[:b0.nbytes])
+            b0.out_arena[:cb].copy_(b0.arena[:cb])
         e1.record()
         torch.cuda.synchronize()
-        copy_gbps = 2 * b0.nbytes * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        copy_gbps = 2 * cb * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ctx.stream_copy_dev(b0.arena.data_ptr(), b0.out_arena.data_ptr(), b0.nbytes, stream)
+        ctx.stream_copy_dev(b0.arena.data_ptr(), b0.out_arena.data_ptr(), cb, stream)
         e0.record()
         for _ in range(5):
-            ctx.stream_copy_dev(b0.arena.data_ptr(), b0.out_arena.data_ptr(), b0.nbytes, stream)
+            ctx.stream_copy_dev(b0.arena.data_ptr(), b0.out_arena.data_ptr(), cb, stream)
         e1.record()
         torch.cuda.synchronize()
-        copy_gbps = {"torch_copy": copy_gbps, "k_stream_copy": 2 * b0.nbytes * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9}
+        copy_gbps = {"torch_copy": copy_gbps, "k_stream_copy": 2 * cb * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9}
 
     if rank == 0:
         alg_bytes = sum(b.alg_bytes for b in batches) / rotate
