@@ -299,6 +299,20 @@ uint32_t unet_synth_flow_hash(int kind, uint64_t seed, uint64_t idx, const unet_
  * one u32 per workgroup (at least 4096 slots). */
 int unet_stream_read_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t bytes,
                          uint32_t* d_sink);
+/* ------------------------------------------------ arena packing (host code, no GPU involved) */
+/* Bytes an arena needs for n records of these lengths, each padded to a 16-byte boundary (at least 16). */
+int unet_pack_size(const uint32_t* len, uint32_t n, uint64_t* arena_bytes);
+/* Copies n separately owned buffers (e.g. the Vec<u8> of each Ipv4QueueEntry, src/protocols.rs:52-57) into one
+ * arena, back to back on 16-byte boundaries, pad bytes zeroed; writes off16[i].  The arena must be 16-byte
+ * aligned and at least unet_pack_size() bytes long. */
+int unet_pack_frames(const uint8_t* const* frames, const uint32_t* len, uint32_t n, uint8_t* arena, uint64_t arena_bytes,
+                     uint32_t* off16);
+/* The same from one length-prefixed byte stream: n records, each a little-endian u32 length followed by that
+ * many bytes, no padding between records.  n_out receives the record count; with arena == NULL only the
+ * count and *arena_bytes are computed (off16/len may be NULL then). */
+int unet_pack_length_prefixed(const uint8_t* stream, uint64_t stream_bytes, uint8_t* arena, uint64_t* arena_bytes,
+                              uint32_t* off16, uint32_t* len, uint32_t cap, uint32_t* n_out);
+
 /* ------------------------------------------------ capture files <-> arenas (host code, no GPU involved) */
 /* What the reference's two devices hand to the stack: tap::read fills a 1514-byte buffer
  * (src/driver/tap.rs:168-173, ETHERNET_FRAME_MAX_SIZE src/devices/ethernet.rs:10), so a longer frame arrives

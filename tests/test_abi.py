@@ -165,3 +165,26 @@ def test_flow_hash_record_on_the_host_matches_the_oracle():
             for cut in (0, 13, 14, 33, 34, 37, 38):
                 assert F.flow_hash_record(frame[:cut], 1) == O.flow_hash_record(frame[:cut], l2)
                 assert F.flow_hash_record(rec[:cut], 0) == O.flow_hash_record(rec[:cut], ifc)
+
+
+def test_arena_packers():
+    """unet_pack_frames / unet_pack_length_prefixed against the Python packer used by the other tests."""
+    import struct
+    from unet_amd import _ffi as F
+    rng = np.random.default_rng(4)
+    frames = [rng.integers(0, 256, size=int(n), dtype=np.uint8).tobytes() for n in [0, 1, 15, 16, 17, 98, 1514, 0, 65535, 33]]
+    ref_arena, ref_off, ref_len = unet_amd.pack_arena(frames, pad_byte=0)
+    for arena, off16, lens in (F.pack_frames_native(frames),
+                               F.pack_length_prefixed(b"".join(struct.pack("<I", len(f)) + f for f in frames))):
+        assert arena.ctypes.data % 16 == 0
+        assert (off16 == ref_off).all() and (lens == ref_len).all() and (arena == ref_arena[:arena.nbytes]).all()
+    a, o, l = F.pack_frames_native([])
+    assert a.nbytes == 16 and len(o) == 0
+    a, o, l = F.pack_length_prefixed(b"")
+    assert a.nbytes == 16 and len(l) == 0
+    with pytest.raises(unet_amd.UnetError, match="truncated length prefix"):
+        F.pack_length_prefixed(struct.pack("<I", 2) + b"ab" + b"\x01\x00")
+    with pytest.raises(unet_amd.UnetError, match="announced"):
+        F.pack_length_prefixed(struct.pack("<I", 9) + b"abc")
+    with pytest.raises(unet_amd.UnetError, match="65535"):
+        F.pack_length_prefixed(struct.pack("<I", 70000) + bytes(70000))

@@ -162,6 +162,9 @@ _SIGS = {
     "unet_synth_len_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_uint64, C.c_uint64, _u32p, C.c_uint32, _u32p]),
     "unet_synth_shard_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(_IfaceC), C.c_uint32, _u8p]),
     "unet_synth_flow_hash": (C.c_uint32, [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(_IfaceC)]),
+    "unet_pack_size": (C.c_int, [_u32p, C.c_uint32, C.POINTER(C.c_uint64)]),
+    "unet_pack_frames": (C.c_int, [C.POINTER(C.c_char_p), _u32p, C.c_uint32, _u8p, C.c_uint64, _u32p]),
+    "unet_pack_length_prefixed": (C.c_int, [_vp, C.c_uint64, _u8p, C.POINTER(C.c_uint64), _u32p, _u32p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "unet_pcap_scan": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp]),
     "unet_pcap_pack": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _u8p, C.c_uint64, _u32p, _u32p, _u64p, C.c_uint32]),
     "unet_pcap_write": (C.c_int, [_u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.c_uint32, _u8p, C.c_uint64, C.POINTER(C.c_uint64)]),
@@ -256,6 +259,35 @@ def synth_flow_hash(kind: int, seed: int, idx: int, iface: Iface) -> int:
     """Flow hash of the 5-tuple that record `idx` of the trace carries (before fault injection)."""
     ic = iface.c()
     return int(load_library().unet_synth_flow_hash(kind, seed, idx, C.byref(ic)))
+
+
+def pack_frames_native(frames: Sequence[bytes]):
+    """unet_pack_frames: separately owned buffers -> (arena, off16, lens), done by the library."""
+    lib = load_library()
+    n = len(frames)
+    lens = np.array([len(f) for f in frames], dtype=np.uint32)
+    need = C.c_uint64(0)
+    _check(lib.unet_pack_size(_np_ptr(lens), n, C.byref(need)))
+    arena = _aligned_u8(need.value)
+    off16 = np.zeros(n, dtype=np.uint32)
+    ptrs = (C.c_char_p * max(n, 1))(*[bytes(f) for f in frames])
+    _check(lib.unet_pack_frames(ptrs, _np_ptr(lens), n, _np_ptr(arena), arena.nbytes, _np_ptr(off16)))
+    return arena, off16, lens
+
+
+def pack_length_prefixed(stream: bytes):
+    """unet_pack_length_prefixed: [u32 length][bytes]... -> (arena, off16, lens)."""
+    lib = load_library()
+    buf = np.frombuffer(stream, dtype=np.uint8)
+    need, n = C.c_uint64(0), C.c_uint32(0)
+    _check(lib.unet_pack_length_prefixed(_np_ptr(buf) if len(stream) else None, len(stream), None, C.byref(need), None, None, 0, C.byref(n)))
+    arena = _aligned_u8(need.value)
+    off16 = np.zeros(n.value, dtype=np.uint32)
+    lens = np.zeros(n.value, dtype=np.uint32)
+    cap = C.c_uint64(arena.nbytes)
+    _check(lib.unet_pack_length_prefixed(_np_ptr(buf) if len(stream) else None, len(stream), _np_ptr(arena), C.byref(cap), _np_ptr(off16),
+                                         _np_ptr(lens), n.value, C.byref(n)))
+    return arena, off16, lens
 
 
 TAP_FRAME_MAX = 1514      # src/driver/tap.rs:170

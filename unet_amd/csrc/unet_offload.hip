@@ -793,6 +793,75 @@ int unet_stream_read_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint
     return UNET_OK;
 }
 
+/* ---------------------------------------------------------------- arena packing */
+int unet_pack_size(const uint32_t* len, uint32_t n, uint64_t* arena_bytes) {
+    if ((n && !len) || !arena_bytes) return fail(UNET_E_INVAL, "null argument");
+    u64 slots = 0;
+    for (u32 i = 0; i < n; i++) {
+        if (len[i] > kMaxLen) return fail(UNET_E_RANGE, "record %u: length %u > 65535", i, len[i]);
+        slots += ((u64)len[i] + 15u) >> 4;
+    }
+    if (slots > 0xffffffffull) return fail(UNET_E_RANGE, "more than 2^32 16-byte slots");
+    *arena_bytes = slots ? slots * 16u : 16u;
+    return UNET_OK;
+}
+
+int unet_pack_frames(const uint8_t* const* frames, const uint32_t* len, uint32_t n, uint8_t* arena, uint64_t arena_bytes,
+                     uint32_t* off16) {
+    if (!arena || !off16 || (n && (!frames || !len))) return fail(UNET_E_INVAL, "null argument");
+    if (((uintptr_t)arena & 15u) != 0) return fail(UNET_E_INVAL, "arena must be 16-byte aligned");
+    u64 need = 0;
+    int rc = unet_pack_size(len, n, &need);
+    if (rc) return rc;
+    if (arena_bytes < need) return fail(UNET_E_RANGE, "arena of %llu bytes, need %llu", (unsigned long long)arena_bytes, (unsigned long long)need);
+    u64 slot = 0;
+    for (u32 i = 0; i < n; i++) {
+        if (len[i] && !frames[i]) return fail(UNET_E_INVAL, "record %u: null buffer", i);
+        const u64 padded = ((u64)len[i] + 15u) & ~15ull;
+        uint8_t* dst = arena + slot * 16u;
+        if (len[i]) memcpy(dst, frames[i], len[i]);
+        memset(dst + len[i], 0, padded - len[i]);
+        off16[i] = (u32)slot;
+        slot += padded >> 4;
+    }
+    if (slot == 0) memset(arena, 0, 16);
+    return UNET_OK;
+}
+
+int unet_pack_length_prefixed(const uint8_t* stream, uint64_t stream_bytes, uint8_t* arena, uint64_t* arena_bytes,
+                              uint32_t* off16, uint32_t* len, uint32_t cap, uint32_t* n_out) {
+    if ((!stream && stream_bytes) || !arena_bytes || !n_out) return fail(UNET_E_INVAL, "null argument");
+    if (arena && (!off16 || !len)) return fail(UNET_E_INVAL, "null table");
+    if (arena && ((uintptr_t)arena & 15u) != 0) return fail(UNET_E_INVAL, "arena must be 16-byte aligned");
+    u64 pos = 0, slot = 0;
+    u32 n = 0;
+    while (pos < stream_bytes) {
+        if (stream_bytes - pos < 4) return fail(UNET_E_INVAL, "record %u: truncated length prefix at byte %llu", n, (unsigned long long)pos);
+        u32 l;
+        memcpy(&l, stream + pos, 4);
+        if (l > kMaxLen) return fail(UNET_E_RANGE, "record %u: length %u > 65535", n, l);
+        if (stream_bytes - pos - 4 < l) return fail(UNET_E_INVAL, "record %u: %u bytes announced, %llu left", n, l, (unsigned long long)(stream_bytes - pos - 4));
+        const u64 padded = ((u64)l + 15u) & ~15ull;
+        if (arena) {
+            if (n >= cap) return fail(UNET_E_RANGE, "more than %u records", cap);
+            if ((slot * 16u) + padded > *arena_bytes) return fail(UNET_E_RANGE, "arena too small");
+            uint8_t* dst = arena + slot * 16u;
+            memcpy(dst, stream + pos + 4, l);
+            memset(dst + l, 0, padded - l);
+            off16[n] = (u32)slot;
+            len[n] = l;
+        }
+        slot += padded >> 4;
+        pos += 4ull + l;
+        if (slot > 0xffffffffull || n == 0xffffffffu) return fail(UNET_E_RANGE, "stream too large");
+        n++;
+    }
+    *n_out = n;
+    if (!arena) *arena_bytes = slot ? slot * 16u : 16u;
+    else if (slot == 0 && *arena_bytes >= 16) memset(arena, 0, 16);
+    return UNET_OK;
+}
+
 /* ---------------------------------------------------------------- capture files */
 int unet_pcap_scan(const uint8_t* file, uint64_t file_bytes, uint32_t max_len, unet_pcap_info* info) {
     if (!file || !info) return fail(UNET_E_INVAL, "null argument");
