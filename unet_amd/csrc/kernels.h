@@ -30,6 +30,9 @@ struct Batch {
 // 64..9000-byte mix: 6.1 TB/s against 5.7 TB/s all non-temporal; 1500-byte packets are unaffected).
 // Knob for experiments (bit set = non-temporal): 1 rows 0/1 of a streamed record, 2 lane-parallel
 // records, 4 the loop past 2 KiB.  ld_stream() is always non-temporal (bandwidth yardstick).
+#ifndef UNET_TX_G4
+#define UNET_TX_G4 1
+#endif
 #ifndef UNET_TX_MID_PATH
 #define UNET_TX_MID_PATH 1
 #endif
@@ -774,9 +777,10 @@ __device__ __forceinline__ void tx_build_one(const TxRows& cur, u32 lane, u32 fr
     if (lane + kWave < nout) tx_store(splice<R>(c, hc), pout + lane + kWave);
 }
 
-// A packet with a payload of at most 8 chunks (128 bytes), built by its own lane: the same virtual-chunk
-// splice as tx_build_one, with every chunk of the packet in this lane's registers.
-constexpr u32 kTxSmallChunks = 8;
+// A packet with a payload of at most 3 chunks (48 bytes: measured break-even with the 4-lane groups), built
+// by its own lane: the same virtual-chunk splice as tx_build_one, with every chunk of the packet in this
+// lane's registers.
+constexpr u32 kTxSmallChunks = 3;
 
 template <int R, u32 SH>
 __device__ __forceinline__ void tx_build_small(const Batch& pay, u32 my_len, u32 my_slot, u32 frame_len,
@@ -811,34 +815,25 @@ __device__ __forceinline__ void tx_build_small(const Batch& pay, u32 my_len, u32
         if (c < nout) tx_store_small(splice<R>(v[c], v[c + 1u]), pout + c);
 }
 
-// Packets of at most 64 chunks (payloads of up to 64 - SH chunks), four at a time, one per 16-lane row of
-// the wave: lane `sub` of a row holds virtual chunks sub, sub+16, sub+32, sub+48 of its row's packet
-// (header chunks from LDS, payload chunks loaded SH chunks further left), the row's payload sum is
-// reduced inside the row, and a chunk's neighbour comes from the next lane of the row -- or, for lane 15,
-// from lane 0's chunk of the next step.  Two groups of four packets are in flight.
-struct TxMidGroup {
+// Packets of at most 4*W chunks (payloads of up to 4*W - SH chunks), 64/W at a time, one per group of W
+// (4, 8 or 16) neighbouring lanes: lane `sub` of a group holds virtual chunks sub, sub+W, sub+2W, sub+3W of
+// its group's packet (header chunks from LDS, payload chunks loaded SH chunks further left), the payload's
+// sum is reduced inside the group, and a chunk's neighbour comes from the next lane of the group -- or,
+// for the group's last lane, from its first lane's chunk of the next step.  Two steps are in flight.
+// `list` holds the tile's packets of this class, in lane order.
+struct TxRowStep {
     u32x4 v0, v1, v2, v3;
-    u32 rec, len, flen, oslot, partial;  // per 16-lane row
-    bool udp, row_live;                  // per 16-lane row
-    bool any;                            // wave-uniform
+    u32 rec, len, flen, oslot, partial;  // per group
+    bool udp, row_live;                  // per group
 };
 
-template <u32 SH>
-__device__ __forceinline__ TxMidGroup issue_tx_mid(const Batch& pay, const Tile& t, u32 my_flen, u32 my_oslot, u32 my_partial,
-                                                   bool my_udp, u64& mid) {
-    const u32 sub = t.lane & 15u, q = t.lane >> 4;
-    TxMidGroup g;
-    g.any = mid != 0ull;
-    u32 r[4];
-    bool have[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        have[k] = mid != 0ull;
-        r[k] = have[k] ? (u32)__builtin_ctzll(mid) : 0u;
-        mid &= mid - 1ull;
-    }
-    g.rec = q == 0u ? r[0] : (q == 1u ? r[1] : (q == 2u ? r[2] : r[3]));
-    g.row_live = q == 0u ? have[0] : (q == 1u ? have[1] : (q == 2u ? have[2] : have[3]));
+template <u32 W, u32 SH>
+__device__ __forceinline__ TxRowStep issue_tx_step(const Batch& pay, const Tile& t, u32 my_flen, u32 my_oslot, u32 my_partial,
+                                                   bool my_udp, const u32* __restrict__ list, u32 first, u32 count) {
+    const u32 sub = t.lane & (W - 1u), k = first + t.lane / W;
+    TxRowStep g;
+    g.row_live = k < count;
+    g.rec = list[g.row_live ? k : 0u];
     g.len = from_lane(t.my_len, g.rec);
     g.flen = from_lane(my_flen, g.rec);
     g.oslot = from_lane(my_oslot, g.rec);
@@ -847,25 +842,28 @@ __device__ __forceinline__ TxMidGroup issue_tx_mid(const Batch& pay, const Tile&
     const u32 slot = from_lane(t.my_slot, g.rec);
     const u32 nin = g.row_live ? (g.len + 15u) >> 4 : 0u;
     const u32 last = nin != 0u ? nin - 1u : 0u;
-    const u32x4* p = reinterpret_cast<const u32x4*>(pay.arena + (g.row_live ? (u64)slot * 16u : 0ull));
+    // an empty payload may sit at the very end of the arena: read the arena's first chunk instead
+    const u32x4* p = reinterpret_cast<const u32x4*>(pay.arena + (nin != 0u ? (u64)slot * 16u : 0ull));
     g.v0 = p[min(sub < SH ? 0u : sub - SH, last)];
-    g.v1 = p[min(sub + 16u - SH, last)];
-    g.v2 = p[min(sub + 32u - SH, last)];
-    g.v3 = p[min(sub + 48u - SH, last)];
+    g.v1 = p[min(sub + W - SH, last)];
+    g.v2 = p[min(sub + 2u * W - SH, last)];
+    g.v3 = p[min(sub + 3u * W - SH, last)];
     return g;
 }
 
-// Lane i of a 16-lane row receives lane i+1's value; lane 15 receives lane 0's `nxt` (its chunk of the
-// next step).
-__device__ __forceinline__ u32 from_next_in_row(u32 v, u32 nxt) {
-    const int wrap = __builtin_amdgcn_update_dpp(0, (int)nxt, 0x11f, 0xf, 0xf, false);  // row_shr:15: lane 15 <- lane 0
-    return (u32)__builtin_amdgcn_update_dpp(wrap, (int)v, 0x101, 0xf, 0xf, false);     // row_shl:1, lane 15 keeps `wrap`
+// Lane i of a group of W receives lane i+1's value; the group's last lane receives its first lane's
+// `nxt` (that lane's chunk of the next step).
+template <u32 W>
+__device__ __forceinline__ u32 from_next_in_group(u32 v, u32 nxt, bool last_of_group) {
+    const u32 wrap = (u32)__builtin_amdgcn_update_dpp(0, (int)nxt, 0x110 + (W - 1u), 0xf, 0xf, false);  // row_shr:W-1
+    const u32 next = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, false);               // row_shl:1
+    return last_of_group ? wrap : next;
 }
 
-template <int R, u32 SH>
-__device__ __forceinline__ void consume_tx_mid(const TxMidGroup& g, u32 lane, uint8_t* __restrict__ out_arena,
-                                               const u32x4* __restrict__ park) {
-    const u32 sub = lane & 15u;
+template <u32 W, int R, u32 SH>
+__device__ __forceinline__ void consume_tx_step(const TxRowStep& g, u32 lane, uint8_t* __restrict__ out_arena,
+                                                const u32x4* __restrict__ park) {
+    const u32 sub = lane & (W - 1u);
     const u32 nin = g.row_live ? (g.len + 15u) >> 4 : 0u, last = nin != 0u ? nin - 1u : 0u;
     const u32 nout = g.row_live ? (g.flen + 15u) >> 4 : 0u;
     const LaneTail lt(g.len);
@@ -874,7 +872,7 @@ __device__ __forceinline__ void consume_tx_mid(const TxMidGroup& g, u32 lane, ui
     u32 acc = 0;
 #define UNET_TXM_MASK(X, I)                                                              \
     {                                                                                    \
-        const u32 m_ = 16u * (I) + sub, k_ = m_ - SH; /* k_ wraps for the header lanes */ \
+        const u32 m_ = W * (I) + sub, k_ = m_ - SH; /* k_ wraps for the header lanes */   \
         X = zero_unless(X, m_ >= SH && k_ < nin);                                        \
         const bool cut_ = partial && k_ == last;                                         \
         X.x &= cut_ ? lt.m0 : 0xffffffffu;                                               \
@@ -889,11 +887,7 @@ __device__ __forceinline__ void consume_tx_mid(const TxMidGroup& g, u32 lane, ui
     UNET_TXM_MASK(x2, 2u)
     UNET_TXM_MASK(x3, 3u)
 #undef UNET_TXM_MASK
-    acc = dpp_add<0x111, 0xf>(acc);
-    acc = dpp_add<0x112, 0xf>(acc);
-    acc = dpp_add<0x114, 0xf>(acc);
-    acc = dpp_add<0x118, 0xf>(acc);  // lane 15 of the row: the payload's exact sum
-    const u32 total = from_lane(acc, (lane & 48u) | 15u);
+    const u32 total = group_sum<W>(acc);  // the payload's exact sum, in every lane of the group
     const u32 ck = bswap16((~fold16(g.partial + bswap16(fold16(total)))) & 0xffffu) << 16;
     const bool hdr_lane = g.row_live && sub < SH;
     const u32x4 hv = park[hdr_lane ? g.rec * SH + sub : 0u];
@@ -905,12 +899,13 @@ __device__ __forceinline__ void consume_tx_mid(const TxMidGroup& g, u32 lane, ui
     x0.w |= ck_lane && g.udp ? ck : 0u;
     x0.z |= ck_lane && !g.udp ? ck : 0u;
     u32x4* pout = reinterpret_cast<u32x4*>(out_arena + (u64)g.oslot * 16u);
+    const bool last_of_group = sub == W - 1u;
 #define UNET_TXM_EMIT(X, NX, NY, I)                                                      \
     {                                                                                    \
         u32x4 h_ = {0, 0, 0, 0};                                                         \
-        h_.x = from_next_in_row(X.x, NX);                                                \
-        if (R > 4) h_.y = from_next_in_row(X.y, NY);                                     \
-        const u32 m_ = 16u * (I) + sub;                                                  \
+        h_.x = from_next_in_group<W>(X.x, NX, last_of_group);                            \
+        if (R > 4) h_.y = from_next_in_group<W>(X.y, NY, last_of_group);                 \
+        const u32 m_ = W * (I) + sub;                                                    \
         if (m_ < nout) tx_store_small(splice<R>(X, h_), pout + m_);                      \
     }
     UNET_TXM_EMIT(x0, x1.x, x1.y, 0u)
@@ -918,6 +913,35 @@ __device__ __forceinline__ void consume_tx_mid(const TxMidGroup& g, u32 lane, ui
     UNET_TXM_EMIT(x2, x3.x, x3.y, 2u)
     UNET_TXM_EMIT(x3, 0u, 0u, 3u)
 #undef UNET_TXM_EMIT
+}
+
+template <u32 W, int R, u32 SH>
+__device__ __forceinline__ void tx_rows_path(const Batch& pay, const Tile& t, bool mine_here, u32 my_flen, u32 my_oslot,
+                                             u32 my_partial, bool my_udp, u32* __restrict__ list,
+                                             uint8_t* __restrict__ out_arena, const u32x4* __restrict__ park) {
+    constexpr u32 kPerStep = kWave / W;
+    const u64 mask = __ballot(mine_here);
+    if (mask == 0ull) return;
+    const u32 count = (u32)__builtin_popcountll(mask);
+    if (mine_here) list[__builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u))] = t.lane;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    u32 next = 0;
+    TxRowStep g0 = issue_tx_step<W, SH>(pay, t, my_flen, my_oslot, my_partial, my_udp, list, next, count), g1;
+    next += kPerStep;
+#pragma nounroll
+    while (true) {
+        g1 = issue_tx_step<W, SH>(pay, t, my_flen, my_oslot, my_partial, my_udp, list, next, count);
+        consume_tx_step<W, R, SH>(g0, t.lane, out_arena, park);
+        if (next >= count) break;
+        next += kPerStep;
+        g0 = issue_tx_step<W, SH>(pay, t, my_flen, my_oslot, my_partial, my_udp, list, next, count);
+        consume_tx_step<W, R, SH>(g1, t.lane, out_arena, park);
+        if (next >= count) break;
+        next += kPerStep;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the list is reused by the next class
+    __builtin_amdgcn_wave_barrier();
 }
 
 // MODE_L3: packet = 28 header bytes + payload.  MODE_L2: 42 header bytes + payload (+ tap::send's pad).
@@ -933,8 +957,10 @@ __global__ __launch_bounds__(kBlock) void k_tx_build(Batch pay, const TxDesc* __
     constexpr u32 SH = MODE == MODE_L2 ? 3u : 2u;    // output chunks that contain header bytes
     constexpr int R = MODE == MODE_L2 ? 6 : 4;       // payload bytes inside the last header chunk
     static_assert(16u * SH - H == (u32)R, "header geometry");
-    __shared__ u32x4 lds[(kBlock / kWave) * TILE * SH];
-    u32x4* park = lds + (threadIdx.x >> 6) * (TILE * SH);
+    constexpr u32 kWaveLds = TILE * SH + (TILE + 3u) / 4u;  // header chunks, then one list entry per packet
+    __shared__ u32x4 lds[(kBlock / kWave) * kWaveLds];
+    u32x4* park = lds + (threadIdx.x >> 6) * kWaveLds;
+    u32* list = reinterpret_cast<u32*>(park + TILE * SH);
     Tile t;
     if (!t.init<TILE>(pay)) return;
     const u32 i = t.first + t.lane;
@@ -954,8 +980,10 @@ __global__ __launch_bounds__(kBlock) void k_tx_build(Batch pay, const TxDesc* __
     else if ((u64)my_oslot * 16u + (((u64)frame_len + 15u) & ~15ull) > out_bytes) st = UNET_TX_E_RANGE_;
     const bool my_go = t.lane < t.cnt && st == UNET_TX_OK_;
     const bool my_small = UNET_TX_SMALL_PATH && my_go && t.my_len <= 16u * kTxSmallChunks;
-    // payloads of up to 64 - SH chunks: the packet fits the four steps of a 16-lane row
+    // payloads of up to 4*W - SH chunks: the packet fits the four steps of a group of W lanes
     const bool my_mid = UNET_TX_MID_PATH && my_go && !my_small && t.my_len <= 16u * (kWave - SH);
+    const bool my_g4 = UNET_TX_G4 && my_mid && t.my_len <= 16u * (16u - SH);
+    const bool my_g8 = my_mid && !my_g4 && t.my_len <= 16u * (32u - SH);
 
     u64 todo = __ballot(my_go && !my_small && !my_mid);
     TxRows A, B, C;
@@ -1033,19 +1061,11 @@ __global__ __launch_bounds__(kBlock) void k_tx_build(Batch pay, const TxDesc* __
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the parked headers are read by lanes 0..SH-1
     __builtin_amdgcn_wave_barrier();
 
-    // ---- mid-size payloads, four packets at a time (its register buffers are free again afterwards)
+    // ---- mid-size payloads, 16, 8 or 4 packets at a time (the register buffers are free again afterwards)
     if (mid_mask != 0ull) {
-        u64 mid = mid_mask;
-        TxMidGroup g0 = issue_tx_mid<SH>(pay, t, frame_len, my_oslot, my_partial, my_udp, mid), g1;
-#pragma nounroll
-        while (true) {
-            g1 = issue_tx_mid<SH>(pay, t, frame_len, my_oslot, my_partial, my_udp, mid);
-            consume_tx_mid<R, SH>(g0, t.lane, out_arena, park);
-            if (!g1.any) break;
-            g0 = issue_tx_mid<SH>(pay, t, frame_len, my_oslot, my_partial, my_udp, mid);
-            consume_tx_mid<R, SH>(g1, t.lane, out_arena, park);
-            if (!g0.any) break;
-        }
+        if (UNET_TX_G4) tx_rows_path<4, R, SH>(pay, t, my_g4, frame_len, my_oslot, my_partial, my_udp, list, out_arena, park);
+        tx_rows_path<8, R, SH>(pay, t, my_g8, frame_len, my_oslot, my_partial, my_udp, list, out_arena, park);
+        tx_rows_path<16, R, SH>(pay, t, my_mid && !my_g4 && !my_g8, frame_len, my_oslot, my_partial, my_udp, list, out_arena, park);
         if (any) {
             UNET_NEXT(A)
             UNET_NEXT(B)
