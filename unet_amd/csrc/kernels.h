@@ -22,26 +22,29 @@ struct Batch {
     u32 n;
 };
 
-// Cache policy of the record loads.  Record bytes are read once, so the wave-wide row loads of a
-// streamed record are non-temporal (pure streaming read: 7.0 TB/s non-temporal vs 6.2 TB/s default on
-// MI355X).  But records are only 16-byte aligned: in the lane-parallel path neighbouring lanes pull
-// pieces of the same 128-byte lines with separate instructions, and a non-temporal load does not
-// leave the line behind for the next touch -- those loads use the default policy (measured on the
-// 64..9000-byte mix: 6.1 TB/s against 5.7 TB/s all non-temporal; 1500-byte packets are unaffected).
-// Knob for experiments (bit set = non-temporal): 1 rows 0/1 of a streamed record, 2 lane-parallel
-// records, 4 the loop past 2 KiB.  ld_stream() is always non-temporal (bandwidth yardstick).
-#ifndef UNET_TX_G4
-#define UNET_TX_G4 1
-#endif
-#ifndef UNET_TX_MID_PATH
-#define UNET_TX_MID_PATH 1
+// Build-time switches for A/B measurements (each path can be compiled out; the wave-cooperative path then
+// takes those records).
+#ifndef UNET_MID_PATH
+#define UNET_MID_PATH 1       // tile_sums: lane groups for records of 81..1024 bytes
 #endif
 #ifndef UNET_TX_SMALL_PATH
-#define UNET_TX_SMALL_PATH 1
+#define UNET_TX_SMALL_PATH 1  // k_tx_build: one lane per packet up to 48-byte payloads
 #endif
-#ifndef UNET_MID_PATH
-#define UNET_MID_PATH 1
+#ifndef UNET_TX_MID_PATH
+#define UNET_TX_MID_PATH 1    // k_tx_build: lane groups for packets of up to 64 chunks
 #endif
+#ifndef UNET_TX_G4
+#define UNET_TX_G4 1          // k_tx_build: groups of 4 lanes for packets of up to 16 chunks
+#endif
+
+// Cache policy of the record loads.  Record bytes are read once, so bulk loads are non-temporal (pure
+// streaming read on MI355X: 7.0 TB/s non-temporal vs 6.2 TB/s default).  But records are only 16-byte
+// aligned, so a record's first and last 128-byte lines are shared with its neighbours, and a
+// non-temporal load does not leave a line behind for the next touch: every load that holds a record's
+// end, and every load of the lane-parallel and lane-group paths (neighbouring lanes or steps pull pieces
+// of the same lines with separate instructions), uses the default policy.  UNET_NT_MASK (bit set =
+// non-temporal) is the experiment knob: 1 the `head` row of a streamed record, 2 lane-parallel records,
+// 4 rows of long transmit payloads.  ld_stream() is always non-temporal.
 #ifndef UNET_NT_MASK
 #define UNET_NT_MASK 1
 #endif
