@@ -1182,7 +1182,7 @@ __global__ __launch_bounds__(kBlock) void k_flow_hash(Batch b, u32* __restrict__
 __global__ __launch_bounds__(kBlock) void k_stream_read(const u32x4* __restrict__ buf, u64 nchunks,
                                                         u32* __restrict__ sink) {
     u32 acc = 0;
-    const u64 per = (nchunks + gridDim.x - 1) / gridDim.x;
+    const u64 per = ((nchunks + gridDim.x - 1) / gridDim.x + 63u) & ~63ull;  // slabs start on 1 KiB boundaries
     const u64 lo = (u64)blockIdx.x * per;
     const u64 hi = lo + per < nchunks ? lo + per : nchunks;
     u64 i = lo + threadIdx.x;
@@ -1201,7 +1201,7 @@ __global__ __launch_bounds__(kBlock) void k_stream_read(const u32x4* __restrict_
 
 // Read+write yardstick: plain copy with the same access pattern (slab per workgroup, 16 bytes per lane).
 __global__ __launch_bounds__(kBlock) void k_stream_copy(const u32x4* __restrict__ src, u32x4* __restrict__ dst, u64 nchunks) {
-    const u64 per = (nchunks + gridDim.x - 1) / gridDim.x;
+    const u64 per = ((nchunks + gridDim.x - 1) / gridDim.x + 63u) & ~63ull;  // slabs start on 1 KiB boundaries
     const u64 lo = (u64)blockIdx.x * per;
     const u64 hi = lo + per < nchunks ? lo + per : nchunks;
     u64 i = lo + threadIdx.x;
