@@ -136,9 +136,12 @@ class Batch:
             self.len = torch.empty(self.n, dtype=torch.int32, device="cuda")
             ctx.synth_len_dev(kind, SEED, first_idx, rel_ptr, self.n, self.len.data_ptr(), stream)
             slots = (self.len.to(torch.int64) + 15) // 16
+            if stride16:  # fixed-stride arena: every record gets stride16 slots (94 = packed for 1500 bytes)
+                assert int(slots.max().item()) <= stride16
+                slots = torch.full_like(slots, stride16)
             self.off = (torch.cumsum(slots, 0) - slots).to(torch.int32)
             self.nbytes = int(slots.sum().item()) * 16
-            self.arena = torch.empty(self.nbytes + 16, dtype=torch.uint8, device="cuda")
+            self.arena = torch.zeros(self.nbytes + 16, dtype=torch.uint8, device="cuda")
             ctx.synth_indexed_dev(kind, SEED, first_idx, rel_ptr, self.n, ifc, self.off.data_ptr(), self.len.data_ptr(),
                                   self.arena.data_ptr(), self.nbytes, stream)
             self.alg_bytes = int(self.len.to(torch.int64).sum().item()) + 8 * self.n  # bytes + 4 (length) + 4 (result)
@@ -256,6 +259,7 @@ def main():
     ap.add_argument("--ext-tcp", type=int, default=None, help="TCP extension on/off (default: on for imix/trace)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--frames", type=int, default=0, help="override records per GPU per batch")
+    ap.add_argument("--stride16", type=int, default=0, help="fixed-stride workloads: record stride in 16-byte slots (default 94 = packed)")
     ap.add_argument("--rotate", type=int, default=0, help="distinct resident batches cycled through (default 6 for hdr20, else 1)")
     ap.add_argument("--total-frames", type=int, default=1 << 30, help="trace workload: records in the whole trace (all GPUs)")
     ap.add_argument("--emulate-world", type=int, default=0, help="single-GPU rehearsal of the sharded path: pretend to be one of W ranks")
@@ -284,6 +288,8 @@ def main():
     shard_world, shard_rank = (args.emulate_world, args.emulate_rank) if args.emulate_world else (world, rank)
 
     kind, n_per_gpu, stride16 = WORKLOADS[args.workload]
+    if args.stride16 and stride16:
+        stride16 = args.stride16
     if args.frames:
         n_per_gpu = args.frames
     ext_tcp = (args.workload in ("imix", "trace")) if args.ext_tcp is None else bool(args.ext_tcp)
