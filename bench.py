@@ -10,6 +10,9 @@ Workloads (BASELINE.json configs):
   imix     8,388,608 mixed 64..9000-byte TCP/UDP/ICMP packets      (configs[3])
   hdr20    16,777,216 bare 20-byte IPv4 headers                    (configs[1])
   trace    a long flow-table trace generated chunk by chunk in HBM (configs[4]; --total-frames)
+  eth1514  4,194,304 Ethernet frames of 1514 bytes judged in L2 mode
+  csum / generate / txbuild / tximix   the other entry points (calculate_checksum, in-place checksum fill,
+           packet building from payloads of 1472 bytes or of IMIX sizes)
 
 One "step" = one launch of the kernel over the rank's whole resident batch.  With N > 1 the global batch
 is N times larger and every rank takes the records whose 5-tuple flow hash % N is its rank (computed
