@@ -48,6 +48,7 @@ WORKLOADS = {
     # the other entry points over the udp1500 batch
     "csum": (unet_amd.SYNTH_UDP1500, 1 << 22, 94),
     "generate": (unet_amd.SYNTH_UDP1500, 1 << 22, 94),
+    "fields": (unet_amd.SYNTH_UDP1500, 1 << 22, 94),
     "txbuild": (unet_amd.SYNTH_UDP1500, 1 << 22, 94),
     "eth1514": (unet_amd.SYNTH_UDP1500, 1 << 22, 94),
     "tximix": (unet_amd.SYNTH_IMIX, 1 << 23, 0),
@@ -59,6 +60,7 @@ DESCRIPTION = {
     "trace": "flow-table trace (2^20 flows, IMIX sizes) generated in HBM in chunks of 16,777,216 records per GPU (BASELINE configs[4])",
     "csum": "calculate_checksum over 4,194,304 x 1500-byte records per GPU (unet_csum_batch_dev)",
     "generate": "transmit-side checksum fill of 4,194,304 x 1500-byte IPv4/UDP packets per GPU, in place (unet_generate_dev)",
+    "fields": "transmit-side checksum values of 4,194,304 x 1500-byte IPv4/UDP packets per GPU, packets left untouched (unet_checksum_fields_dev)",
     "txbuild": "4,194,304 x 1500-byte IPv4/UDP packets per GPU built from 1472-byte payloads + descriptors (unet_tx_build_dev)",
     "tximix": "8,388,608 IPv4/UDP packets per GPU built from payloads of IMIX sizes (36-8972 bytes) + descriptors (unet_tx_build_dev)",
     "eth1514": "4,194,304 x 1514-byte Ethernet frames per GPU (IPv4/UDP inside, built by unet_tx_build_dev in L2 mode, faults injected), judged in L2 mode",
@@ -152,8 +154,9 @@ class Batch:
         self.out = torch.zeros(self.n, dtype=torch.int32, device="cuda")
         if op == "csum":
             self.alg_bytes -= 2 * self.n      # 2-byte results
-        elif op == "generate":
+        elif op in ("generate", "fields"):
             self.alg_bytes += self.n          # 4 bytes of checksum fields + 1 status byte instead of a 4-byte result
+            self.status = torch.zeros(self.n, dtype=torch.uint8, device="cuda")
         elif op == "tximix":
             # the resident IMIX records serve as payloads: a record of L bytes gives an L-28-byte payload, so the
             # built packets have the IMIX sizes again
@@ -220,6 +223,10 @@ class Batch:
             off_ptr = None if self.stride16 else self.off.data_ptr()
             self.ctx.generate_dev(self.arena.data_ptr(), self.nbytes, off_ptr, self.stride16, self.len.data_ptr(), self.n,
                                   self.out.data_ptr(), self.stream)
+        elif self.op == "fields":
+            off_ptr = None if self.stride16 else self.off.data_ptr()
+            self.ctx.checksum_fields_dev(self.arena.data_ptr(), self.nbytes, off_ptr, self.stride16, self.len.data_ptr(), self.n,
+                                         self.out.data_ptr(), self.status.data_ptr(), self.stream)
         elif self.op in ("txbuild", "tximix"):
             self.build()
         elif self.op == "eth1514":
@@ -376,10 +383,10 @@ def main():
     # rotated over several distinct batches (consecutive index ranges of the same trace) so that no
     # launch finds its input in cache.
     rotate = args.rotate if args.rotate else (6 if kind == unet_amd.SYNTH_IPV4_HDR20 else 1)
-    op = args.workload if args.workload in ("csum", "generate", "txbuild", "eth1514", "tximix") else "verify"
+    op = args.workload if args.workload in ("csum", "generate", "fields", "txbuild", "eth1514", "tximix") else "verify"
     batches = [Batch(ctx, stream, kind, ifc, r * n_global, n_global, shard_world, shard_rank, stride16, op) for r in range(rotate)]
     b0 = batches[0]
-    kernel = {"csum": "k_csum", "generate": "k_generate", "txbuild": "k_tx_build<MODE_L3>", "tximix": "k_tx_build<MODE_L3>", "eth1514": "k_verify<MODE_L2>"}.get(op, "k_ipv4_validate_rows" if kind == unet_amd.SYNTH_IPV4_HDR20 else "k_verify<MODE_L3>")
+    kernel = {"csum": "k_csum", "generate": "k_generate", "fields": "k_generate<read only>", "txbuild": "k_tx_build<MODE_L3>", "tximix": "k_tx_build<MODE_L3>", "eth1514": "k_verify<MODE_L2>"}.get(op, "k_ipv4_validate_rows" if kind == unet_amd.SYNTH_IPV4_HDR20 else "k_verify<MODE_L3>")
     torch.cuda.synchronize()
 
     # ---- timed region
@@ -406,8 +413,8 @@ def main():
         ctx.verify_dev(b0.out_arena.data_ptr(), b0.out_bytes, None, b0.ostride, b0.olen.data_ptr(), b0.n, b0.rx, b0.out.data_ptr(), stream)
     if op == "tximix":
         ctx.verify_dev(b0.out_arena.data_ptr(), b0.out_bytes, b0.ooff.data_ptr(), 0, b0.olen.data_ptr(), b0.n, b0.rx, b0.out.data_ptr(), stream)
-    if op == "csum":
-        b0.out.zero_()  # 16-bit checksums are not verdicts: nothing to count
+    if op in ("csum", "fields"):
+        b0.out.zero_()  # checksum values are not verdicts: nothing to count
     d_cnt = b0.counts()
     torch.cuda.synchronize()
     local_cnt = d_cnt.cpu().numpy().copy()

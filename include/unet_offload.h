@@ -180,6 +180,18 @@ int unet_verify(unet_ctx* ctx, const uint8_t* arena, uint64_t arena_bytes, const
 int unet_generate_dev(unet_ctx* ctx, void* stream, uint8_t* d_arena, uint64_t arena_bytes,
                       const uint32_t* d_off16, uint32_t stride16, const uint32_t* d_len, uint32_t n,
                       uint8_t* d_status);
+
+/* The same two values without touching the packets: fields[i] = what the send path would store at bytes
+ * 10..11 (IPv4 header checksum) and at the UDP / ICMP checksum field, as numbers (store them big-endian);
+ * {0, 0} when status[i] != 0.  A pure read pass -- for callers that keep the packets elsewhere (the host
+ * entry point unet_generate uses it: 4 bytes per packet travel back instead of the arena). */
+typedef struct unet_tx_fields {
+    uint16_t ip_csum;
+    uint16_t l4_csum;
+} unet_tx_fields;
+int unet_checksum_fields_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_t arena_bytes,
+                             const uint32_t* d_off16, uint32_t stride16, const uint32_t* d_len, uint32_t n,
+                             unet_tx_fields* d_fields, uint8_t* d_status);
 int unet_generate(unet_ctx* ctx, uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16,
                   uint32_t stride16, const uint32_t* len, uint32_t n, uint8_t* status);
 

@@ -415,6 +415,38 @@ def test_generate_matches_oracle_and_roundtrips(offload):
     assert set(res["verdict"][filled].tolist()) <= {Verdict.ACCEPT_UDP, Verdict.ACCEPT_ICMP_ECHO, Verdict.ACCEPT_ICMP_ECHOREPLY}
 
 
+def test_checksum_fields_match_generate(offload):
+    """unet_checksum_fields_dev leaves the packets alone and returns exactly the values the in-place fill (and the
+    oracle's) stores."""
+    torch = torch_mod()
+    rng = np.random.default_rng(43)
+    ifc = unet_amd.Iface(ext_tcp=True)
+    arena, off16, lens = unet_amd.synth_host(unet_amd.SYNTH_IMIX, SEED, 500, 8000, ifc)
+    arena = arena.copy()
+    for i in range(0, 8000, 3):  # junk in the checksum fields must not matter
+        o = int(off16[i]) * 16
+        if lens[i] >= 28:
+            arena[o + 10:o + 12] = rng.integers(0, 256, size=2, dtype=np.uint8)
+    exp_arena, exp_status = O.generate_batch(arena, off16, lens)
+    d_arena, d_off, d_len = dev(arena), dev(off16), dev(lens)
+    d_fields = torch.full((8000,), -1, dtype=torch.int32, device="cuda")
+    d_status = torch.full((8000,), 0xEE, dtype=torch.uint8, device="cuda")
+    offload.checksum_fields_dev(d_arena.data_ptr(), arena.nbytes, d_off.data_ptr(), 0, d_len.data_ptr(), 8000, d_fields.data_ptr(),
+                                d_status.data_ptr(), stream())
+    torch.cuda.synchronize()
+    assert (d_arena.cpu().numpy() == arena).all()
+    status = d_status.cpu().numpy()
+    fields = d_fields.cpu().numpy().view(np.uint32)
+    assert (status == exp_status).all() and (status == 0).sum() > 500
+    for i in np.flatnonzero(status == 0):
+        o = int(off16[i]) * 16
+        ip = (int(exp_arena[o + 10]) << 8) | int(exp_arena[o + 11])
+        f = o + (26 if exp_arena[o + 9] == 17 else 22)
+        l4 = (int(exp_arena[f]) << 8) | int(exp_arena[f + 1])
+        assert int(fields[i]) == ip | (l4 << 16), i
+    assert (fields[status != 0] == 0).all()
+
+
 # ------------------------------------------------------------------ flow hash
 
 def test_flow_hash_matches_oracle(offload):

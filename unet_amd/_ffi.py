@@ -144,6 +144,7 @@ _SIGS = {
     "unet_verify_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
     "unet_verify": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
     "unet_generate_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, _u8p]),
+    "unet_checksum_fields_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, _vp, _u8p]),
     "unet_generate": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, _u8p]),
     "unet_tx_build_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, _vp, C.c_uint32, C.POINTER(_IfaceC), _u8p,
                                     C.c_uint64, _u32p, _u32p, _u8p]),
@@ -471,6 +472,9 @@ class Offload:
         ic = iface.c()
         _check(self.lib.unet_tx_build_dev(self.h, stream, d_pay_arena, pay_bytes, d_pay_off16, pay_stride16, d_pay_len, d_desc, n,
                                           C.byref(ic), d_out_arena, out_bytes, d_out_off16, d_out_len, d_status))
+
+    def checksum_fields_dev(self, d_arena, arena_bytes, d_off16, stride16, d_len, n, d_fields, d_status, stream=None):
+        _check(self.lib.unet_checksum_fields_dev(self.h, stream, d_arena, arena_bytes, d_off16, stride16, d_len, n, d_fields, d_status))
 
     def count_verdicts_dev(self, d_results, n, d_counts, stream=None):
         _check(self.lib.unet_count_verdicts_dev(self.h, stream, d_results, n, d_counts))

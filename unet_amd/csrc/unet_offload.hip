@@ -490,9 +490,28 @@ int unet_generate_dev(unet_ctx* ctx, void* stream, uint8_t* d_arena, uint64_t ar
     Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
     if (arena_too_small(arena_bytes)) return fail(UNET_E_INVAL, "arena must hold at least 16 bytes");
     switch (pick_tile(arena_bytes, n)) {
-        case 16: hipLaunchKernelGGL(k_generate<16>, dim3(tiles_grid(n, 16)), dim3(kBlock), 0, pick(ctx, stream), b, d_arena, d_status); break;
-        case 32: hipLaunchKernelGGL(k_generate<32>, dim3(tiles_grid(n, 32)), dim3(kBlock), 0, pick(ctx, stream), b, d_arena, d_status); break;
-        default: hipLaunchKernelGGL(k_generate<64>, dim3(tiles_grid(n, 64)), dim3(kBlock), 0, pick(ctx, stream), b, d_arena, d_status); break;
+        case 16: hipLaunchKernelGGL((k_generate<16, true>), dim3(tiles_grid(n, 16)), dim3(kBlock), 0, pick(ctx, stream), b, d_arena, (u32*)nullptr, d_status); break;
+        case 32: hipLaunchKernelGGL((k_generate<32, true>), dim3(tiles_grid(n, 32)), dim3(kBlock), 0, pick(ctx, stream), b, d_arena, (u32*)nullptr, d_status); break;
+        default: hipLaunchKernelGGL((k_generate<64, true>), dim3(tiles_grid(n, 64)), dim3(kBlock), 0, pick(ctx, stream), b, d_arena, (u32*)nullptr, d_status); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return UNET_OK;
+}
+
+int unet_checksum_fields_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_t arena_bytes, const uint32_t* d_off16,
+                             uint32_t stride16, const uint32_t* d_len, uint32_t n, unet_tx_fields* d_fields, uint8_t* d_status) {
+    static_assert(sizeof(unet_tx_fields) == 4, "field pair layout");
+    int rc = check_batch(ctx, d_arena, d_off16, stride16, d_len, n);
+    if (rc) return rc;
+    if (n == 0) return UNET_OK;
+    if (!d_fields) return fail(UNET_E_INVAL, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
+    if (arena_too_small(arena_bytes)) return fail(UNET_E_INVAL, "arena must hold at least 16 bytes");
+    switch (pick_tile(arena_bytes, n)) {
+        case 16: hipLaunchKernelGGL((k_generate<16, false>), dim3(tiles_grid(n, 16)), dim3(kBlock), 0, pick(ctx, stream), b, (uint8_t*)nullptr, (u32*)d_fields, d_status); break;
+        case 32: hipLaunchKernelGGL((k_generate<32, false>), dim3(tiles_grid(n, 32)), dim3(kBlock), 0, pick(ctx, stream), b, (uint8_t*)nullptr, (u32*)d_fields, d_status); break;
+        default: hipLaunchKernelGGL((k_generate<64, false>), dim3(tiles_grid(n, 64)), dim3(kBlock), 0, pick(ctx, stream), b, (uint8_t*)nullptr, (u32*)d_fields, d_status); break;
     }
     HIP_TRY(hipGetLastError());
     return UNET_OK;
@@ -508,11 +527,34 @@ int unet_generate(unet_ctx* c, uint8_t* arena, uint64_t arena_bytes, const uint3
     Batch b;
     int rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b);
     if (rc) return rc;
-    if ((rc = ensure(c, c->d_out, (size_t)n))) return rc;
-    rc = unet_generate_dev(c, nullptr, (uint8_t*)c->d_arena.p, arena_bytes, b.off16, b.stride16, b.len, n, (uint8_t*)c->d_out.p);
+    // the GPU computes the two checksum values per packet; only those 4 bytes (and the status) travel
+    // back, and are stored into the caller's packets here
+    if ((rc = ensure(c, c->d_out, (size_t)n * 5))) return rc;
+    unet_tx_fields* d_fields = (unet_tx_fields*)c->d_out.p;
+    uint8_t* d_status = (uint8_t*)c->d_out.p + (size_t)n * 4;
+    rc = unet_checksum_fields_dev(c, nullptr, (const uint8_t*)c->d_arena.p, arena_bytes, b.off16, b.stride16, b.len, n, d_fields, d_status);
     if (rc) return rc;
-    if (status && (rc = d2h_sync(c, status, c->d_out.p, (size_t)n))) return rc;
-    return d2h_sync(c, arena, c->d_arena.p, arena_bytes);
+    std::vector<unet_tx_fields> fields;
+    std::vector<uint8_t> st;
+    try {
+        fields.resize(n);
+        st.resize(n);
+    } catch (const std::bad_alloc&) {
+        return fail(UNET_E_NOMEM, "out of host memory");
+    }
+    if ((rc = d2h_sync(c, fields.data(), d_fields, (size_t)n * 4))) return rc;
+    if ((rc = d2h_sync(c, st.data(), d_status, (size_t)n))) return rc;
+    for (u32 i = 0; i < n; i++) {
+        if (status) status[i] = st[i];
+        if (st[i] != 0) continue;
+        uint8_t* p = arena + (off16 ? (u64)off16[i] : (u64)i * stride16) * 16u;
+        p[10] = (uint8_t)(fields[i].ip_csum >> 8);
+        p[11] = (uint8_t)fields[i].ip_csum;
+        uint8_t* f = p + (p[9] == 17 ? 26 : 22);  // UDP checksum field / ICMP checksum field behind a 20-byte header
+        f[0] = (uint8_t)(fields[i].l4_csum >> 8);
+        f[1] = (uint8_t)fields[i].l4_csum;
+    }
+    return UNET_OK;
 }
 
 int unet_tx_build_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload_arena, uint64_t payload_arena_bytes,
