@@ -21,8 +21,11 @@ GPUs on the data path; only the 32 per-verdict counters are all-reduced (RCCL) a
 Rank 0 prints one JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -65,6 +68,46 @@ DESCRIPTION = {
     "tximix": "8,388,608 IPv4/UDP packets per GPU built from payloads of IMIX sizes (36-8972 bytes) + descriptors (unet_tx_build_dev)",
     "eth1514": "4,194,304 x 1514-byte Ethernet frames per GPU (IPv4/UDP inside, built by unet_tx_build_dev in L2 mode, faults injected), judged in L2 mode",
 }
+
+
+KERNEL_SOURCES = ("unet_amd/csrc/kernels.h", "unet_amd/csrc/csum_core.h", "unet_amd/csrc/parse.h")
+
+
+def kernels_sha256():
+    """Digest of the kernel sources: ties a committed PMC traffic figure to the code it was measured on."""
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def committed_traffic(workload, frames, single_gpu):
+    """(bytes per launch or None, where the figure comes from).  The figure is a committed PMC measurement
+    (profiles/traffic.json), not a measurement of this run: it is only reported when it was taken on this
+    workload, this batch size and exactly these kernel sources."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(workload)
+    except (OSError, ValueError):
+        return None, "profiles/traffic.json unreadable"
+    if not rec:
+        return None, "no committed PMC pass for this workload"
+    if rec.get("frames") != frames or not single_gpu:
+        return None, "committed PMC pass was taken on another batch size or sharding"
+    if rec.get("kernels_sha256") != kernels_sha256():
+        return None, f"stale: the committed PMC pass ({rec.get('source', '?')}) was taken on other kernel sources"
+    return rec["traffic_bytes"], f"committed PMC pass, not this run: {rec.get('source', '?')}"
+
+
+def self_launch(argv, gpus):
+    """`python bench.py --gpus N` with no launcher around it: start N fresh ranks under torch.distributed.run as a
+    child process (this process has not touched the GPU and never does) and hand back its exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd)
 
 
 def cpu_baseline(kind, ifc, budget_s):
@@ -276,13 +319,29 @@ def main():
     ap.add_argument("--emulate-rank", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--all-on-gpu0", action="store_true", help="rehearsal on a one-GPU box: every rank uses cuda:0")
+    ap.add_argument("--dry-run", action="store_true", help="start the ranks, rendezvous, print who is there, stop before any GPU call")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.dry_run:
+        import torch.distributed as dist
+        seen = [rank]
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.zeros(world, dtype=torch.int64)
+            t[rank] = rank + 1
+            dist.all_reduce(t)
+            seen = [int(x) - 1 for x in t.tolist()]
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": seen, "workload": args.workload}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the offload has no CPU path")
     if args.all_on_gpu0:
@@ -366,17 +425,20 @@ def main():
                            "timing": "sum of HIP-event times around the verify launches (max over ranks); generation excluded",
                            "end_to_end_Gpkt_s_incl_generation": frames_all / wall_all / 1e9},
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                             "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": "k_verify<MODE_L3>",
+                             "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "traffic_source": "no PMC pass for the chunked trace",
+                             "kernels_sha256": kernels_sha256(), "kernel": "k_verify<MODE_L3>",
                              "kernel_ms": kernel_s * 1e3 / n_chunks, "algorithmic_bytes_per_launch": alg_bytes_total // n_chunks},
                 "hbm_GBps_all_gpus": bytes_all / kernel_s_max / 1e9,
                 "verdict_counts": {Verdict(i).name: int(c) for i, c in enumerate(cnt) if c},
             }
-            if world == 1 and args.cpu_seconds > 0:
-                line["cpu_baseline"] = cpu_baseline(kind, ifc, args.cpu_seconds)
-            print(json.dumps(line), flush=True)
         ctx.close()
         if dist:
             dist.destroy_process_group()
+        if rank == 0:
+            # the CPU path beside every scaling point: rank 0 times it once the GPUs are idle
+            if args.cpu_seconds > 0:
+                line["cpu_baseline"] = cpu_baseline(kind, ifc, args.cpu_seconds)
+            print(json.dumps(line), flush=True)
         return
 
     # ---- resident batches.  A workload whose arena is not far larger than the 256 MiB Infinity Cache is
@@ -497,15 +559,8 @@ def main():
     if rank == 0:
         alg_bytes = sum(b.alg_bytes for b in batches) / rotate
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC passes of this same command (tools/pmc_traffic.py), if the
-        # committed measurement matches this workload and batch size
-        traffic = None
-        try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(args.workload)
-            if rec and rec["frames"] == b0.n and shard_world == 1:
-                traffic = rec["traffic_bytes"]
-        except (OSError, ValueError, KeyError):
-            pass
+        # HBM bytes per launch from the PMC passes of this same command (tools/pmc_traffic.py)
+        traffic, traffic_source = committed_traffic(args.workload, b0.n, shard_world == 1)
         if shard_world == 1:
             sharding = "single GPU, contiguous trace indices"
         elif kind == unet_amd.SYNTH_IPV4_HDR20:
@@ -532,7 +587,8 @@ def main():
                        "collectives": "none on the data path; 32 u64 verdict counters all-reduced (RCCL) after the timed region",
                        "inputs": "generated in HBM by unet_synth_indexed_dev before the timed region"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": kernel,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernels_sha256": kernels_sha256(), "kernel": kernel,
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "stream_read_GBps": stream_gbps, "frac_of_stream_read": achieved / stream_gbps,
                          **({"d2d_copy_GBps": copy_gbps} if copy_gbps else {})},
@@ -540,12 +596,14 @@ def main():
             "verdict_counts": {Verdict(i).name: int(c) for i, c in enumerate(cnt) if c},
             "parity_check": parity,
         }
-        if world == 1 and args.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(kind, ifc, args.cpu_seconds)
-        print(json.dumps(line), flush=True)
     ctx.close()
     if dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # the CPU path beside every scaling point: rank 0 times it once the GPUs are idle
+        if args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(kind, ifc, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
