@@ -117,6 +117,11 @@ const char* unet_last_error(void);
 int unet_device_count(void);
 /* Block until all work queued on the context's own streams is done. */
 int unet_sync(unet_ctx* ctx);
+/* Records per wavefront are chosen from the batch's mean record length.  The *_dev entry points cannot see the
+ * lengths (they are in device memory) and estimate it as 16*stride16, or arena_bytes / n without a stride --
+ * wrong for an arena with gaps.  A caller that knows better says so here (0 = back to the estimate).  Only
+ * speed depends on it, never results. */
+int unet_hint_mean_len(unet_ctx* ctx, uint32_t mean_len);
 
 /* -------------------------------------------------- frame arena layout */
 /* A batch is `n` records in one byte arena.  Record i starts at byte 16*off16[i]

@@ -143,6 +143,7 @@ _SIGS = {
     "unet_ipv4_validate": (C.c_int, [_vp, _u8p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
     "unet_verify_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
     "unet_verify": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
+    "unet_hint_mean_len": (C.c_int, [_vp, C.c_uint32]),
     "unet_generate_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, _u8p]),
     "unet_checksum_fields_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, _vp, _u8p]),
     "unet_generate": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, _u8p]),
@@ -417,6 +418,9 @@ class Offload:
         _check(self.lib.unet_verify(self.h, _np_ptr(arena), arena.nbytes, _np_ptr(off16), stride16, _np_ptr(lens), n,
                                     C.byref(ic), _np_ptr(out)))
         return out
+
+    def hint_mean_len(self, mean_len: int):
+        _check(self.lib.unet_hint_mean_len(self.h, int(mean_len)))
 
     def verify_frames(self, frames: Sequence[bytes], iface: Iface) -> np.ndarray:
         arena, off16, lens = pack_arena(frames)

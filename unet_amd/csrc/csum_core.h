@@ -66,6 +66,21 @@ __device__ __forceinline__ u32 wave_sum(u32 v) {
     return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// Minimum / maximum over the 64 lanes of a wave, returned wave-uniform.  Same DPP ladder as wave_sum; a lane whose
+// DPP source does not exist keeps its own value (`old` operand), which is harmless for min and max.
+template <bool MAX>
+__device__ __forceinline__ u32 wave_minmax(u32 v) {
+#define UNET_MM_STEP(CTRL, ROWS)                                                                      \
+    {                                                                                                 \
+        const u32 o_ = (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWS, 0xf, false);      \
+        v = MAX ? (o_ > v ? o_ : v) : (o_ < v ? o_ : v);                                              \
+    }
+    UNET_MM_STEP(0x111, 0xf) UNET_MM_STEP(0x112, 0xf) UNET_MM_STEP(0x114, 0xf) UNET_MM_STEP(0x118, 0xf)
+    UNET_MM_STEP(0x142, 0xa) UNET_MM_STEP(0x143, 0xc)
+#undef UNET_MM_STEP
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __device__ __forceinline__ u32 rdlane(u32 v, u32 lane) {
     return (u32)__builtin_amdgcn_readlane((int)v, (int)lane);
 }

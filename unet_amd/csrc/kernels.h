@@ -27,6 +27,9 @@ struct Batch {
 #ifndef UNET_MID_PATH
 #define UNET_MID_PATH 1       // tile_sums: lane groups for records of 81..1024 bytes
 #endif
+#ifndef UNET_SPAN_PATH
+#define UNET_SPAN_PATH 0      // tile_sums: tiles of short records staged in LDS as one coalesced byte range
+#endif
 #ifndef UNET_TX_SMALL_PATH
 #define UNET_TX_SMALL_PATH 1  // k_tx_build: one lane per packet up to 48-byte payloads
 #endif
@@ -92,6 +95,7 @@ struct Tile {
     u32 first, cnt, lane;
     u32 my_len, my_slot;
     bool my_ok;
+    const u32x4* my_hdr;  // set by tile_sums: where the lane's own record starts in LDS (at least its first six chunks)
     template <int TILE>
     __device__ __forceinline__ bool init(const Batch& b) {
         lane = threadIdx.x & 63u;
@@ -105,10 +109,13 @@ struct Tile {
         if (lane < cnt) {
             const u32 i = first + lane;
             my_len = b.len[i];
-            my_slot = b.off16 ? b.off16[i] : i * b.stride16;
+            // slots are 32-bit: a fixed-stride batch whose last record starts past slot 2^32 - 1 (an arena of
+            // 64 GiB or more) must not wrap onto another record
+            const u64 slot = b.off16 ? (u64)b.off16[i] : (u64)i * b.stride16;
+            my_slot = (u32)slot;
             // the record and its pad to 16 bytes must lie inside the arena
-            const u64 end = (u64)my_slot * 16u + (((u64)my_len + 15u) & ~15ull);
-            my_ok = my_len <= kMaxLen && end <= b.arena_bytes;
+            const u64 end = slot * 16u + (((u64)my_len + 15u) & ~15ull);
+            my_ok = my_len <= kMaxLen && slot <= 0xffffffffull && end <= b.arena_bytes;
         }
         return true;
     }
@@ -344,13 +351,86 @@ __device__ __forceinline__ void rows_path(const Batch& b, const Tile& t, bool mi
     }
 }
 
-// Exact sum of the lane's own record (0 for lanes without a valid record).  On return the wave's LDS
-// area `park` holds, for record j, chunks 0..5 at park[j*7 .. j*7+5] (if PARK_HDR) -- visible to every
-// lane of the wave.
+// N fully coalesced streaming 1 KiB loads of the chunks [0, span) at p (indices past the end re-read the last
+// chunk), all issued before the first is parked in LDS.
+template <u32 N>
+__device__ __forceinline__ void stage_span(const u32x4* __restrict__ p, u32 lane, u32 span, u32x4* __restrict__ park) {
+    u32x4 v[N];
+#pragma unroll
+    for (u32 k = 0; k < N; ++k) v[k] = ld_stream(p + min(k * kWave + lane, span - 1u));
+#pragma unroll
+    for (u32 k = 0; k < N; ++k) park[k * kWave + lane] = v[k];
+}
+
+// A tile made only of short records (at most 7 chunks each) that lie close together -- any packed or
+// fixed-stride batch of short frames: the byte range that holds them is staged in the wave's LDS area with whole
+// 1 KiB rows, and every lane then sums its own record out of LDS.  One lane loading its own 64-byte record
+// straight from memory makes every load instruction touch 32 different 128-byte lines; here each line is
+// requested once.  Returns false (nothing done) when the tile does not qualify.
+template <int TILE>
+__device__ __forceinline__ bool span_path(const Batch& b, Tile& t, u32 my_nch, u32x4* __restrict__ park, u32* total) {
+    constexpr u32 kCap = (u32)TILE * kLdsChunksPerRec;  // chunks in the wave's park area
+    const bool in = t.lane < t.cnt;
+    const bool fits = !in || (t.my_ok && my_nch <= kLdsChunksPerRec && t.my_slot <= 0xfffffff0u);
+    if (__ballot(fits) != ~0ull) return false;
+    const bool some = in && my_nch != 0u;
+    const u32 lo = wave_minmax<false>(some ? t.my_slot : 0xffffffffu);
+    const u32 end = wave_minmax<true>(some ? t.my_slot + my_nch : 0u);
+    t.my_hdr = park;
+    *total = 0;
+    if (end <= lo) return true;  // nothing but empty records
+    // start on a 128-byte line when the range still fits then
+    const u32 base = end - (lo & ~7u) <= kCap ? (lo & ~7u) : lo;
+    const u32 span = end - base;
+    if (span > kCap) return false;
+    const u32x4* p = reinterpret_cast<const u32x4*>(b.arena) + (u64)base;
+    switch ((span + kWave - 1u) / kWave) {
+        case 1: stage_span<1>(p, t.lane, span, park); break;
+        case 2: stage_span<2>(p, t.lane, span, park); break;
+        case 3: stage_span<3>(p, t.lane, span, park); break;
+        case 4: stage_span<4>(p, t.lane, span, park); break;
+        case 5: stage_span<5>(p, t.lane, span, park); break;
+        case 6: stage_span<6>(p, t.lane, span, park); break;
+        default: stage_span<7>(p, t.lane, span, park); break;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const u32 rel = some ? t.my_slot - base : 0u;
+    const u32x4* mine = park + rel;
+    t.my_hdr = mine;
+    const u32 max_nch = wave_minmax<true>(my_nch);
+    const LaneTail tail(t.my_len);
+    const bool partial = (t.my_len & 15u) != 0u;
+    const u32 nfull = t.my_len >> 4;
+    u32 acc = 0;
+#pragma unroll
+    for (u32 k = 0; k < kLdsChunksPerRec; ++k) {
+        if (k < max_nch) {  // wave-uniform
+            u32x4 c = mine[k];
+            const u32x4 cut = tail.apply(c);
+            const bool whole = k < nfull, last = partial && k == nfull;
+            c.x = whole ? c.x : (last ? cut.x : 0u);
+            c.y = whole ? c.y : (last ? cut.y : 0u);
+            c.z = whole ? c.z : (last ? cut.z : 0u);
+            c.w = whole ? c.w : (last ? cut.w : 0u);
+            acc = sum_chunk(c, acc);
+        }
+    }
+    *total = some ? acc : 0u;
+    return true;
+}
+
+// Exact sum of the lane's own record (0 for lanes without a valid record).  On return t.my_hdr points at the
+// lane's own record in LDS: at least its chunks 0..5 (if PARK_HDR; stale or foreign bytes past the record's end).
 template <int TILE, bool PARK_HDR>
-__device__ __forceinline__ u32 tile_sums(const Batch& b, const Tile& t, u32x4* __restrict__ park) {
+__device__ __forceinline__ u32 tile_sums(const Batch& b, Tile& t, u32x4* __restrict__ park) {
     u32x4* mine = park + t.lane * kLdsChunksPerRec;  // only meaningful for lane < TILE
     const u32 my_nch = t.my_ok ? (t.my_len + 15u) >> 4 : 0u;
+    if (UNET_SPAN_PATH) {
+        u32 span_total;
+        if (span_path<TILE>(b, t, my_nch, park, &span_total)) return span_total;
+    }
+    t.my_hdr = mine;
     const bool my_small = t.my_ok && my_nch >= 1u && my_nch <= kSmallChunks;
     const bool my_mid = UNET_MID_PATH && t.my_ok && my_nch > kSmallChunks && my_nch <= kMidChunks;
     const bool my_row4 = my_mid && my_nch <= kRow4Chunks;
@@ -516,7 +596,7 @@ __global__ __launch_bounds__(kBlock, TILE == 64 ? 5 : 6) void k_verify(Batch b, 
     u32 res = 0;  // V_NONE for records whose length/offset is out of range
     if (t.my_ok) {
         LdsFetch f;
-        f.w = reinterpret_cast<const u32*>(park + t.lane * kLdsChunksPerRec);
+        f.w = reinterpret_cast<const u32*>(t.my_hdr);
         const Parsed P = parse_record<MODE>(f, t.my_len, ifc);
         res = P.kind == K_DONE ? P.res : finalize_record(P, total);
     }
@@ -605,7 +685,7 @@ __global__ __launch_bounds__(kBlock, TILE == 64 ? 5 : 6) void k_generate(Batch b
     u32 st = V_DROP_L3_TRUNCATED;  // also reported for out-of-range lengths/offsets
     u32 my_fields = 0;
     if (t.my_ok && t.my_len >= 20u) {
-        const u32* w = reinterpret_cast<const u32*>(park + t.lane * kLdsChunksPerRec);
+        const u32* w = reinterpret_cast<const u32*>(t.my_hdr);
         const u32 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
         const u32 proto = (w2 >> 8) & 0xffu;
         const u32 vhl = w0 & 0xffu;
@@ -1234,7 +1314,7 @@ __device__ __forceinline__ u64 trace_index(u64 first_idx, const u32* __restrict_
 // Layer 1 (+ the post-checksum payload flip): one wave per record, 16 bytes per lane.
 __global__ __launch_bounds__(kBlock) void k_synth_raw(int kind, u64 seed, u64 first_idx, const u32* __restrict__ rel_idx,
                                                       u32 n, const u32* __restrict__ off16,
-                                                      const u32* __restrict__ len, uint8_t* __restrict__ arena) {
+                                                      const u32* __restrict__ len, uint8_t* __restrict__ arena, u64 arena_bytes) {
     const u32 lane = threadIdx.x & 63u;
     const u32 rec = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
     if (rec >= n) return;
@@ -1243,6 +1323,8 @@ __global__ __launch_bounds__(kBlock) void k_synth_raw(int kind, u64 seed, u64 fi
     const unetsynth::Shape s = unetsynth::shape_of(kind, seed, idx);
     const u32 flen = len[rec];
     const u64 slot = off16[rec];
+    // a table that does not describe this trace, or points outside the arena, writes nothing
+    if (flen != s.len || slot * 16u + (((u64)flen + 15u) & ~15ull) > arena_bytes) return;
     u32 fpos = 0, fmask = 0;
     const bool has_flip = unetsynth::flip_of(kind, key, s, &fpos, &fmask);
     u64* dst = reinterpret_cast<u64*>(arena + slot * 16u);
@@ -1261,7 +1343,8 @@ __global__ __launch_bounds__(kBlock) void k_synth_raw(int kind, u64 seed, u64 fi
 // Layer 2: one lane per record builds the headers (with their checksums) and stores them.
 __global__ __launch_bounds__(kBlock) void k_synth_hdr(int kind, u64 seed, u64 first_idx, const u32* __restrict__ rel_idx,
                                                       u32 n, u32 unicast, u32 broadcast,
-                                                      const u32* __restrict__ off16, uint8_t* __restrict__ arena) {
+                                                      const u32* __restrict__ off16, const u32* __restrict__ len,
+                                                      uint8_t* __restrict__ arena, u64 arena_bytes) {
     const u32 rec = blockIdx.x * kBlock + threadIdx.x;
     if (rec >= n) return;
     const u64 idx = trace_index(first_idx, rel_idx, rec);
@@ -1270,6 +1353,12 @@ __global__ __launch_bounds__(kBlock) void k_synth_hdr(int kind, u64 seed, u64 fi
     const unetsynth::Tuple tp = unetsynth::tuple_of(kind, seed, idx, s, unicast, broadcast);
     uint8_t h[96];
     const u32 hb = unetsynth::build_header(kind, key, s, tp, unicast, h);
+    if (kind == unetsynth::kKindHdr20) {
+        if ((u64)rec * 20u + 20u > arena_bytes) return;
+    } else {
+        // same rule as k_synth_raw: a mismatched table writes nothing
+        if (len[rec] != s.len || (u64)off16[rec] * 16u + (((u64)s.len + 15u) & ~15ull) > arena_bytes) return;
+    }
     uint8_t* base = kind == unetsynth::kKindHdr20 ? arena + (u64)rec * 20u : arena + (u64)off16[rec] * 16u;
     u32* dst = reinterpret_cast<u32*>(base);
     for (u32 i = 0; i < hb; i += 4) {

@@ -131,6 +131,9 @@ struct unet_ctx {
     hipEvent_t copied = nullptr;
     DevBuf d_arena, d_off, d_len, d_out, d_aux, d_tx, d_tx_tab;
     CopyPool* pool = nullptr;
+    int tile_override = 0;        // UNET_TILE, read once at unet_open
+    bool hdr_plain = false;       // UNET_HDR_PLAIN, read once at unet_open
+    u32 mean_len_hint = 0;        // unet_hint_mean_len
 };
 
 namespace {
@@ -199,13 +202,16 @@ int check_batch(unet_ctx* ctx, const void* arena, const void* off16, u32 stride1
 inline bool arena_too_small(u64 arena_bytes) { return arena_bytes < 16; }
 // Records per wave: long records want short tiles (fine-grained tail of the launch), short records
 // want many lanes busy in the lane-parallel phase.
-inline int pick_tile(u64 arena_bytes, u32 n) {
-    if (const char* e = getenv("UNET_TILE")) {
-        const int t = atoi(e);
-        return t <= 16 ? 16 : (t <= 32 ? 32 : 64);
-    }
-    const u64 mean_len = arena_bytes / n;
-    return mean_len >= 1024 ? 16 : (mean_len >= 256 ? 32 : 64);
+inline int tile_for_mean(u64 mean_len) { return mean_len >= 1024 ? 16 : (mean_len >= 256 ? 32 : 64); }
+// The device-pointer entry points cannot see the lengths: the mean record size is the caller's hint if one was
+// given (unet_hint_mean_len), else the fixed stride, else arena_bytes / n (right for packed arenas).  The
+// host-pointer entry points pass the true mean.
+inline int pick_tile(const unet_ctx* c, u64 arena_bytes, u32 stride16, u32 n, u64 true_mean = ~0ull) {
+    if (c->tile_override) return c->tile_override;
+    if (true_mean != ~0ull) return tile_for_mean(true_mean);
+    if (c->mean_len_hint) return tile_for_mean(c->mean_len_hint);
+    if (stride16) return tile_for_mean((u64)stride16 * 16u);
+    return tile_for_mean(arena_bytes / n);
 }
 
 inline hipStream_t pick(unet_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->s_comp; }
@@ -216,14 +222,18 @@ inline u32 tiles_grid(u32 n, u32 tile) {
 
 // Shared body of the host-pointer batch calls: upload arena + tables, leave device views in `b`.
 int upload_batch(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16, uint32_t stride16,
-                 const uint32_t* len, uint32_t n, Batch* b) {
+                 const uint32_t* len, uint32_t n, Batch* b, u32* mean_len) {
     // every record (plus its pad to 16 bytes) must lie inside the caller's arena
+    u64 sum_len = 0;
     for (u32 i = 0; i < n; i++) {
         if (len[i] > kMaxLen) return fail(UNET_E_RANGE, "record %u: length %u > 65535", i, len[i]);
         const u64 slot = off16 ? off16[i] : (u64)i * stride16;
+        if (slot > 0xffffffffull) return fail(UNET_E_RANGE, "record %u starts past 2^32 16-byte slots", i);
         const u64 end = slot * 16u + (((u64)len[i] + 15u) & ~15ull);
         if (end > arena_bytes) return fail(UNET_E_RANGE, "record %u ends at byte %llu, arena is %llu bytes (records are read in 16-byte chunks)", i, (unsigned long long)end, (unsigned long long)arena_bytes);
+        sum_len += len[i];
     }
+    if (mean_len) *mean_len = (u32)(sum_len / n);
     int rc;
     if ((rc = ensure(c, c->d_arena, arena_bytes))) return rc;
     if ((rc = ensure(c, c->d_len, (size_t)n * 4))) return rc;
@@ -241,11 +251,45 @@ int upload_batch(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const 
     return UNET_OK;
 }
 
+int launch_verify(hipStream_t s, const Batch& b, const unet_iface* iface, int tile, u32* d_out) {
+    const IfaceDev ifc = to_dev(iface);
+    const u32 n = b.n;
+#define UNET_LAUNCH_VERIFY(M, T) \
+    hipLaunchKernelGGL((k_verify<M, T>), dim3(tiles_grid(n, T)), dim3(kBlock), 0, s, b, ifc, d_out)
+    if (iface->mode == UNET_MODE_L2) {
+        if (tile == 16) UNET_LAUNCH_VERIFY(MODE_L2, 16);
+        else if (tile == 32) UNET_LAUNCH_VERIFY(MODE_L2, 32);
+        else UNET_LAUNCH_VERIFY(MODE_L2, 64);
+    } else {
+        if (tile == 16) UNET_LAUNCH_VERIFY(MODE_L3, 16);
+        else if (tile == 32) UNET_LAUNCH_VERIFY(MODE_L3, 32);
+        else UNET_LAUNCH_VERIFY(MODE_L3, 64);
+    }
+#undef UNET_LAUNCH_VERIFY
+    HIP_TRY(hipGetLastError());
+    return UNET_OK;
+}
+
+// The host-pointer entry points know the true mean record length; it steers the tile choice of the *_dev call
+// they make.
+struct MeanScope {
+    unet_ctx* c;
+    u32 old;
+    MeanScope(unet_ctx* ctx, u32 mean) : c(ctx), old(ctx->mean_len_hint) { c->mean_len_hint = mean ? mean : 1u; }
+    ~MeanScope() { c->mean_len_hint = old; }
+};
+
 }  // namespace
 
 extern "C" {
 
 const char* unet_last_error(void) { return g_err; }
+
+int unet_hint_mean_len(unet_ctx* c, uint32_t mean_len) {
+    if (!c) return fail(UNET_E_INVAL, "null context");
+    c->mean_len_hint = mean_len;
+    return UNET_OK;
+}
 
 int unet_device_count(void) {
     int n = 0;
@@ -282,11 +326,23 @@ int unet_open(int device_id, unet_ctx** out_ctx) {
     const int hw = (int)std::thread::hardware_concurrency();
     if (hw > 0 && threads > hw) threads = hw;
     threads = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
-    c->pool = new (std::nothrow) CopyPool(threads - 1);
+    // a thread that cannot be started (process or thread limits) is not fatal: copy with fewer helpers
+    for (; threads >= 1 && !c->pool; threads = threads > 1 ? 1 : 0) {
+        try {
+            c->pool = new CopyPool(threads - 1);
+        } catch (...) {
+            c->pool = nullptr;
+        }
+    }
     if (!c->pool) {
         unet_close(c);
-        return fail(UNET_E_NOMEM, "out of host memory");
+        return fail(UNET_E_NOMEM, "cannot create the staging-copy pool");
     }
+    if (const char* t = getenv("UNET_TILE")) {
+        const int v = atoi(t);
+        c->tile_override = v <= 16 ? 16 : (v <= 32 ? 32 : 64);
+    }
+    c->hdr_plain = getenv("UNET_HDR_PLAIN") != nullptr;
     *out_ctx = c;
     return UNET_OK;
 }
@@ -330,7 +386,7 @@ int unet_csum_batch_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uin
     HIP_TRY(hipSetDevice(ctx->device));
     Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
     if (arena_too_small(arena_bytes)) return fail(UNET_E_INVAL, "arena must hold at least 16 bytes");
-    switch (pick_tile(arena_bytes, n)) {
+    switch (pick_tile(ctx, arena_bytes, stride16, n)) {
         case 16: hipLaunchKernelGGL(k_csum<16>, dim3(tiles_grid(n, 16)), dim3(kBlock), 0, pick(ctx, stream), b, d_seeds, d_out); break;
         case 32: hipLaunchKernelGGL(k_csum<32>, dim3(tiles_grid(n, 32)), dim3(kBlock), 0, pick(ctx, stream), b, d_seeds, d_out); break;
         default: hipLaunchKernelGGL(k_csum<64>, dim3(tiles_grid(n, 64)), dim3(kBlock), 0, pick(ctx, stream), b, d_seeds, d_out); break;
@@ -347,7 +403,9 @@ int unet_csum_batch(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, con
     if (!off16 && stride16 == 0) return fail(UNET_E_INVAL, "need an offset table or a non-zero stride");
     HIP_TRY(hipSetDevice(c->device));
     Batch b;
-    int rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b);
+    u32 mean = 0;
+    int rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b, &mean);
+    MeanScope hint(c, mean);
     if (rc) return rc;
     if ((rc = ensure(c, c->d_out, (size_t)n * 2))) return rc;
     const uint16_t* d_seeds = nullptr;
@@ -402,7 +460,7 @@ int unet_ipv4_validate_dev(unet_ctx* ctx, void* stream, const uint8_t* d_hdrs, u
     const u32 ext = iface->ext_tcp ? 1u : 0u;
     // whole workgroups of 1024 headers take the row kernel; the remainder (< 1024) the per-lane kernel
     const u32 per_block = (kBlock / kWave) * kHdrPerWave;
-    const u32 full_blocks = getenv("UNET_HDR_PLAIN") ? 0u : n / per_block;
+    const u32 full_blocks = ctx->hdr_plain ? 0u : n / per_block;
     const u32 done = full_blocks * per_block;
     if (full_blocks)
         hipLaunchKernelGGL(k_ipv4_validate_rows, dim3(full_blocks), dim3(kBlock), 0, pick(ctx, stream), (const u32x4*)d_hdrs, ext,
@@ -444,23 +502,8 @@ int unet_verify_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_
     if (iface->mode != UNET_MODE_L3 && iface->mode != UNET_MODE_L2) return fail(UNET_E_INVAL, "bad iface mode %d", iface->mode);
     HIP_TRY(hipSetDevice(ctx->device));
     Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
-    const IfaceDev ifc = to_dev(iface);
-    const int tile = pick_tile(arena_bytes, n);
-    hipStream_t s = pick(ctx, stream);
-#define UNET_LAUNCH_VERIFY(M, T) \
-    hipLaunchKernelGGL((k_verify<M, T>), dim3(tiles_grid(n, T)), dim3(kBlock), 0, s, b, ifc, (u32*)d_out)
-    if (iface->mode == UNET_MODE_L2) {
-        if (tile == 16) UNET_LAUNCH_VERIFY(MODE_L2, 16);
-        else if (tile == 32) UNET_LAUNCH_VERIFY(MODE_L2, 32);
-        else UNET_LAUNCH_VERIFY(MODE_L2, 64);
-    } else {
-        if (tile == 16) UNET_LAUNCH_VERIFY(MODE_L3, 16);
-        else if (tile == 32) UNET_LAUNCH_VERIFY(MODE_L3, 32);
-        else UNET_LAUNCH_VERIFY(MODE_L3, 64);
-    }
-#undef UNET_LAUNCH_VERIFY
-    HIP_TRY(hipGetLastError());
-    return UNET_OK;
+    if (arena_too_small(arena_bytes)) return fail(UNET_E_INVAL, "arena must hold at least 16 bytes");
+    return launch_verify(pick(ctx, stream), b, iface, pick_tile(ctx, arena_bytes, stride16, n), (u32*)d_out);
 }
 
 int unet_verify(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16, uint32_t stride16,
@@ -471,7 +514,9 @@ int unet_verify(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const u
     if (!off16 && stride16 == 0) return fail(UNET_E_INVAL, "need an offset table or a non-zero stride");
     HIP_TRY(hipSetDevice(c->device));
     Batch b;
-    int rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b);
+    u32 mean = 0;
+    int rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b, &mean);
+    MeanScope hint(c, mean);
     if (rc) return rc;
     if ((rc = ensure(c, c->d_out, (size_t)n * 4))) return rc;
     rc = unet_verify_dev(c, nullptr, b.arena, b.arena_bytes, b.off16, b.stride16, b.len, n, iface, (unet_result*)c->d_out.p);
@@ -489,7 +534,7 @@ int unet_generate_dev(unet_ctx* ctx, void* stream, uint8_t* d_arena, uint64_t ar
     HIP_TRY(hipSetDevice(ctx->device));
     Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
     if (arena_too_small(arena_bytes)) return fail(UNET_E_INVAL, "arena must hold at least 16 bytes");
-    switch (pick_tile(arena_bytes, n)) {
+    switch (pick_tile(ctx, arena_bytes, stride16, n)) {
         case 16: hipLaunchKernelGGL((k_generate<16, true>), dim3(tiles_grid(n, 16)), dim3(kBlock), 0, pick(ctx, stream), b, d_arena, (u32*)nullptr, d_status); break;
         case 32: hipLaunchKernelGGL((k_generate<32, true>), dim3(tiles_grid(n, 32)), dim3(kBlock), 0, pick(ctx, stream), b, d_arena, (u32*)nullptr, d_status); break;
         default: hipLaunchKernelGGL((k_generate<64, true>), dim3(tiles_grid(n, 64)), dim3(kBlock), 0, pick(ctx, stream), b, d_arena, (u32*)nullptr, d_status); break;
@@ -508,7 +553,7 @@ int unet_checksum_fields_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena
     HIP_TRY(hipSetDevice(ctx->device));
     Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
     if (arena_too_small(arena_bytes)) return fail(UNET_E_INVAL, "arena must hold at least 16 bytes");
-    switch (pick_tile(arena_bytes, n)) {
+    switch (pick_tile(ctx, arena_bytes, stride16, n)) {
         case 16: hipLaunchKernelGGL((k_generate<16, false>), dim3(tiles_grid(n, 16)), dim3(kBlock), 0, pick(ctx, stream), b, (uint8_t*)nullptr, (u32*)d_fields, d_status); break;
         case 32: hipLaunchKernelGGL((k_generate<32, false>), dim3(tiles_grid(n, 32)), dim3(kBlock), 0, pick(ctx, stream), b, (uint8_t*)nullptr, (u32*)d_fields, d_status); break;
         default: hipLaunchKernelGGL((k_generate<64, false>), dim3(tiles_grid(n, 64)), dim3(kBlock), 0, pick(ctx, stream), b, (uint8_t*)nullptr, (u32*)d_fields, d_status); break;
@@ -525,7 +570,9 @@ int unet_generate(unet_ctx* c, uint8_t* arena, uint64_t arena_bytes, const uint3
     if (!off16 && stride16 == 0) return fail(UNET_E_INVAL, "need an offset table or a non-zero stride");
     HIP_TRY(hipSetDevice(c->device));
     Batch b;
-    int rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b);
+    u32 mean = 0;
+    int rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b, &mean);
+    MeanScope hint(c, mean);
     if (rc) return rc;
     // the GPU computes the two checksum values per packet; only those 4 bytes (and the status) travel
     // back, and are stored into the caller's packets here
@@ -575,7 +622,7 @@ int unet_tx_build_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload_aren
 #define UNET_TX_LAUNCH(M, T)                                                                                             \
     hipLaunchKernelGGL((k_tx_build<M, T>), dim3(tiles_grid(n, T)), dim3(kBlock), 0, pick(ctx, stream), b, (const TxDesc*)d_desc, ifc, \
                        d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status)
-    const int tile = pick_tile(payload_arena_bytes, n);
+    const int tile = pick_tile(ctx, payload_arena_bytes, payload_stride16, n);
     if (iface->mode == UNET_MODE_L2) {
         if (tile == 16) UNET_TX_LAUNCH(MODE_L2, 16);
         else if (tile == 32) UNET_TX_LAUNCH(MODE_L2, 32);
@@ -620,7 +667,9 @@ int unet_tx_build(unet_ctx* c, const uint8_t* payload_arena, uint64_t payload_ar
     if (out_arena_bytes < need) return fail(UNET_E_RANGE, "output arena of %llu bytes, need %llu", (unsigned long long)out_arena_bytes, (unsigned long long)need);
     HIP_TRY(hipSetDevice(c->device));
     Batch b;
-    if ((rc = upload_batch(c, payload_arena, payload_arena_bytes, payload_off16, payload_stride16, payload_len, n, &b))) return rc;
+    u32 mean = 0;
+    if ((rc = upload_batch(c, payload_arena, payload_arena_bytes, payload_off16, payload_stride16, payload_len, n, &b, &mean))) return rc;
+    MeanScope hint(c, mean);
     // tables: descriptors | output offsets | output lengths | status
     const size_t o_desc = 0, o_off = (size_t)n * sizeof(unet_tx_desc), o_len = o_off + (size_t)n * 4, o_st = o_len + (size_t)n * 4;
     if ((rc = ensure(c, c->d_tx_tab, o_st + n))) return rc;
@@ -782,11 +831,11 @@ int unet_synth_indexed_dev(unet_ctx* ctx, void* stream, int kind, uint64_t seed,
     hipStream_t s = pick(ctx, stream);
     if (kind != UNET_SYNTH_IPV4_HDR20) {
         const u32 grid = (n + (kBlock / kWave) - 1) / (kBlock / kWave);
-        hipLaunchKernelGGL(k_synth_raw, dim3(grid), dim3(kBlock), 0, s, kind, seed, first_idx, d_rel_idx, n, d_off16, d_len, d_arena);
+        hipLaunchKernelGGL(k_synth_raw, dim3(grid), dim3(kBlock), 0, s, kind, seed, first_idx, d_rel_idx, n, d_off16, d_len, d_arena, arena_bytes);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(k_synth_hdr, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, kind, seed, first_idx, d_rel_idx, n,
-                       iface->unicast, iface->broadcast, d_off16, d_arena);
+                       iface->unicast, iface->broadcast, d_off16, d_len, d_arena, arena_bytes);
     HIP_TRY(hipGetLastError());
     return UNET_OK;
 }
