@@ -171,6 +171,21 @@ int unet_verify(unet_ctx* ctx, const uint8_t* arena, uint64_t arena_bytes, const
                 uint32_t stride16, const uint32_t* len, uint32_t n, const unet_iface* iface,
                 unet_result* out);
 
+/* unet_verify for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops
+ * such as the stack's own drain loop handing over a few hundred frames at a time, harnesses that forbid
+ * hipMalloc).  It has no counterpart in the reference.  Same arguments, same kernel and bit-identical results as
+ * unet_verify, but the device-side staging lives in a static device array inside the library (about 8.8 MB,
+ * held by every GPU the library runs on until the process ends) and the call performs no hipMalloc / hipFree or
+ * any other allocation.  Limits, checked with UNET_E_RANGE: at most UNET_STATIC_MAX_RECORDS records, all of them
+ * ending inside the first UNET_STATIC_MAX_ARENA_BYTES bytes of the arena.  All contexts on one GPU share that
+ * GPU's array, which keeps the previous call's bytes: calls that overlap on one GPU race with each other (one
+ * caller thread per GPU, like every other host-pointer entry point of a context). */
+#define UNET_STATIC_MAX_RECORDS 65536u
+#define UNET_STATIC_MAX_ARENA_BYTES (8u << 20)
+int unet_verify_static(unet_ctx* ctx, const uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16,
+                       uint32_t stride16, const uint32_t* len, uint32_t n, const unet_iface* iface,
+                       unet_result* out);
+
 /* ------------------- a7, a9, a10: udp::send / icmp::send / create_ip_header */
 /* Transmit side: every record is an L3 packet (IPv4 header with IHL 5 + UDP or ICMP
  * message) whose checksum fields hold arbitrary bytes.  Fills, in place:

@@ -143,6 +143,7 @@ _SIGS = {
     "unet_ipv4_validate": (C.c_int, [_vp, _u8p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
     "unet_verify_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
     "unet_verify": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
+    "unet_verify_static": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
     "unet_hint_mean_len": (C.c_int, [_vp, C.c_uint32]),
     "unet_generate_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, _u8p]),
     "unet_checksum_fields_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, _vp, _u8p]),
@@ -417,6 +418,16 @@ class Offload:
         ic = iface.c()
         _check(self.lib.unet_verify(self.h, _np_ptr(arena), arena.nbytes, _np_ptr(off16), stride16, _np_ptr(lens), n,
                                     C.byref(ic), _np_ptr(out)))
+        return out
+
+    def verify_static(self, arena: np.ndarray, off16, lens: np.ndarray, iface: Iface, stride16: int = 0) -> np.ndarray:
+        """unet_verify_static: the same verdicts through the library's static device scratch (no allocation)."""
+        arena, off16, lens = self._prep(arena, off16, lens)
+        n = len(lens)
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        ic = iface.c()
+        _check(self.lib.unet_verify_static(self.h, _np_ptr(arena), arena.nbytes, _np_ptr(off16), stride16, _np_ptr(lens), n,
+                                           C.byref(ic), _np_ptr(out)))
         return out
 
     def hint_mean_len(self, mean_len: int):

@@ -122,6 +122,38 @@ class CopyPool {
 
 }  // namespace
 
+// ---- device memory of unet_verify_static: held by every GPU the library runs on until the process ends.
+// Layout per call: [len table | offset table | arena bytes] from byte 0 (one H2D copy), results at kStaticOutAt.
+constexpr u32 kStaticMaxRecords = UNET_STATIC_MAX_RECORDS;
+constexpr u64 kStaticMaxArena = UNET_STATIC_MAX_ARENA_BYTES;
+constexpr u64 kStaticInBytes = 2ull * kStaticMaxRecords * 4u + kStaticMaxArena;  // both tables + arena
+constexpr u64 kStaticOutAt = kStaticInBytes;                                     // multiple of 256
+constexpr u64 kStaticBytes = kStaticOutAt + (u64)kStaticMaxRecords * 4u;
+static_assert(kStaticInBytes % 256 == 0, "results start on a 256-byte boundary");
+static_assert(kStaticInBytes <= kStageBytes && (u64)kStaticMaxRecords * 4u <= kStageBytes, "one pinned staging buffer holds a whole call");
+static __device__ __align__(256) uint8_t scratch[kStaticBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+uint8_t* g_scratch_ptr[kMaxDevices];  // per device: each GPU holds its own copy of the array at its own address
+
+// Device address of `scratch` on device `dev` (which must be the current device).  In host code the array's
+// name is only a handle for hipGetSymbolAddress, never an address a kernel or a copy may be given.
+int static_scratch_of(int dev, uint8_t** out) {
+    if (dev < 0 || dev >= kMaxDevices) return fail(UNET_E_NODEV, "device %d: at most %d devices are supported", dev, kMaxDevices);
+    std::lock_guard<std::mutex> g(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) return fail(UNET_E_HIP, "hipGetSymbolAddress(scratch) on device %d failed: %s", dev, hipGetErrorString(e));
+        g_scratch_ptr[dev] = (uint8_t*)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return UNET_OK;
+}
+}  // namespace
+
 struct unet_ctx {
     int device = 0;
     hipStream_t s_comp = nullptr;  // kernels (and D2H of results)
@@ -134,6 +166,7 @@ struct unet_ctx {
     int tile_override = 0;        // UNET_TILE, read once at unet_open
     bool hdr_plain = false;       // UNET_HDR_PLAIN, read once at unet_open
     u32 mean_len_hint = 0;        // unet_hint_mean_len
+    uint8_t* scratch_dev = nullptr;  // this device's copy of the static scratch array
 };
 
 namespace {
@@ -343,6 +376,11 @@ int unet_open(int device_id, unet_ctx** out_ctx) {
         c->tile_override = v <= 16 ? 16 : (v <= 32 ? 32 : 64);
     }
     c->hdr_plain = getenv("UNET_HDR_PLAIN") != nullptr;
+    int rc = static_scratch_of(device_id, &c->scratch_dev);
+    if (rc) {
+        unet_close(c);
+        return rc;
+    }
     *out_ctx = c;
     return UNET_OK;
 }
@@ -522,6 +560,55 @@ int unet_verify(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const u
     rc = unet_verify_dev(c, nullptr, b.arena, b.arena_bytes, b.off16, b.stride16, b.len, n, iface, (unet_result*)c->d_out.p);
     if (rc) return rc;
     return d2h_sync(c, out, c->d_out.p, (size_t)n * 4);
+}
+
+// No counterpart in the reference: unet_verify for callers that cannot allocate.  Same kernel; the device-side
+// staging that unet_verify keeps in hipMalloc'ed buffers lives in the static `scratch` array instead, reached
+// only through the per-device address taken at unet_open, and the host side uses the pinned buffers the
+// context already owns.  Nothing here allocates or frees.
+int unet_verify_static(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16, uint32_t stride16,
+                       const uint32_t* len, uint32_t n, const unet_iface* iface, unet_result* out) {
+    if (!c) return fail(UNET_E_INVAL, "null context");
+    if (n == 0) return UNET_OK;
+    if (!arena || !len || !iface || !out) return fail(UNET_E_INVAL, "null argument");
+    if (!off16 && stride16 == 0) return fail(UNET_E_INVAL, "need an offset table or a non-zero stride");
+    if (iface->mode != UNET_MODE_L3 && iface->mode != UNET_MODE_L2) return fail(UNET_E_INVAL, "bad iface mode %d", iface->mode);
+    if (n > kStaticMaxRecords)
+        return fail(UNET_E_RANGE, "unet_verify_static takes at most %u records per call, got %u (use unet_verify)", kStaticMaxRecords, n);
+    // the records, wherever they sit in the caller's arena, must end inside its first kStaticMaxArena bytes
+    u64 used = 16, sum_len = 0;
+    for (u32 i = 0; i < n; i++) {
+        if (len[i] > kMaxLen) return fail(UNET_E_RANGE, "record %u: length %u > 65535", i, len[i]);
+        const u64 slot = off16 ? off16[i] : (u64)i * stride16;
+        const u64 end = slot * 16u + (((u64)len[i] + 15u) & ~15ull);
+        if (end > arena_bytes) return fail(UNET_E_RANGE, "record %u ends at byte %llu, arena is %llu bytes (records are read in 16-byte chunks)", i, (unsigned long long)end, (unsigned long long)arena_bytes);
+        if (end > used) used = end;
+        sum_len += len[i];
+    }
+    if (used > kStaticMaxArena)
+        return fail(UNET_E_RANGE, "unet_verify_static takes records inside the arena's first %llu bytes, these reach byte %llu (use unet_verify)",
+                    (unsigned long long)kStaticMaxArena, (unsigned long long)used);
+    HIP_TRY(hipSetDevice(c->device));
+    // one staging image [len | off16 | arena], one H2D copy, one launch, one D2H copy, all on the compute stream
+    const u64 tab = ((u64)n * 4u + 15u) & ~15ull;
+    const u64 at_off = tab, at_arena = off16 ? 2u * tab : tab;
+    HIP_TRY(hipEventSynchronize(c->pinned_free[0]));
+    HIP_TRY(hipEventSynchronize(c->pinned_free[1]));
+    uint8_t* pin = (uint8_t*)c->pinned[0];
+    memcpy(pin, len, (size_t)n * 4u);
+    if (off16) memcpy(pin + at_off, off16, (size_t)n * 4u);
+    memcpy(pin + at_arena, arena, used);
+    uint8_t* dev = c->scratch_dev;  // never the array's name: that is not a device address in host code
+    HIP_TRY(hipMemcpyAsync(dev, pin, at_arena + used, hipMemcpyHostToDevice, c->s_comp));
+    Batch b{dev + at_arena, used, off16 ? (const u32*)(dev + at_off) : nullptr, stride16, (const u32*)dev, n};
+    u32* d_out = (u32*)(dev + kStaticOutAt);
+    const int tile = c->tile_override ? c->tile_override : tile_for_mean(sum_len / n);
+    int rc = launch_verify(c->s_comp, b, iface, tile, d_out);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->pinned[1], d_out, (size_t)n * 4u, hipMemcpyDeviceToHost, c->s_comp));
+    HIP_TRY(hipStreamSynchronize(c->s_comp));
+    memcpy(out, c->pinned[1], (size_t)n * 4u);
+    return UNET_OK;
 }
 
 /* ---------------------------------------------------------------- transmit path */
