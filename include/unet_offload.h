@@ -30,6 +30,7 @@ extern "C" {
 #define UNET_E_HIP (-3)     /* a HIP runtime call failed; see unet_last_error() */
 #define UNET_E_NOMEM (-4)   /* host or device allocation failed */
 #define UNET_E_RANGE (-5)   /* a frame length > 65535 or an offset outside the arena */
+#define UNET_E_BUSY (-6)    /* unet_verify_async: UNET_ASYNC_DEPTH batches are already in flight */
 
 /* ---------------------------------------------------------------- verdicts */
 /* One code per outcome of the reference's receive path; the FIRST failing check
@@ -171,6 +172,23 @@ int unet_verify(unet_ctx* ctx, const uint8_t* arena, uint64_t arena_bytes, const
                 uint32_t stride16, const uint32_t* len, uint32_t n, const unet_iface* iface,
                 unet_result* out);
 
+/* The drain loop's way of using the GPU without threads of its own (src/protocols.rs:83-97 runs on the stack's
+ * main thread): unet_verify_async stages batch k and returns while the GPU works on it, the caller packs batch
+ * k+1 and hands it over as well, then collects the verdicts of batch k with unet_wait.  Up to UNET_ASYNC_DEPTH
+ * batches are in flight, each on a stream of its own (copy in, kernel, copy out overlap between batches); one
+ * more submit returns UNET_E_BUSY.  The arena and tables may be reused as soon as unet_verify_async returns;
+ * `out` must stay valid until unet_wait(ticket) returns, which is when it holds the results.  Same kernel and
+ * bit-identical results as unet_verify. */
+#define UNET_ASYNC_DEPTH 2
+#define UNET_TICKET_NONE 0xffffffffu
+typedef struct unet_ticket {
+    uint32_t id;
+} unet_ticket;
+int unet_verify_async(unet_ctx* ctx, const uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16,
+                      uint32_t stride16, const uint32_t* len, uint32_t n, const unet_iface* iface,
+                      unet_result* out, unet_ticket* ticket);
+int unet_wait(unet_ctx* ctx, unet_ticket ticket);
+
 /* unet_verify for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops
  * such as the stack's own drain loop handing over a few hundred frames at a time, harnesses that forbid
  * hipMalloc).  It has no counterpart in the reference.  Same arguments, same kernel and bit-identical results as
@@ -266,10 +284,18 @@ int unet_tx_build(unet_ctx* ctx, const uint8_t* payload_arena, uint64_t payload_
 
 /* ------------------------------------------------------------ counters */
 /* Histogram of verdicts: d_counts[v] += number of results with verdict v (UNET_V_COUNT
- * u64 slots, caller zeroes them).  The reference keeps no counters; these are what a
+ * u64 slots in device memory, caller zeroes them; NULL = the context's own counters, see unet_counters).  The reference keeps no counters; these are what a
  * multi-GPU job sums at the end (the only value that ever crosses GPUs). */
 int unet_count_verdicts_dev(unet_ctx* ctx, void* stream, const unet_result* d_results, uint32_t n,
                             uint64_t* d_counts);
+/* Every context keeps UNET_V_COUNT counters of its own in device memory: the host-pointer entry points
+ * (unet_verify, unet_verify_async, unet_verify_static, unet_ipv4_validate) add the verdicts of every record they
+ * judge, and unet_count_verdicts_dev adds to them when d_counts is NULL.  unet_counters waits for the context's
+ * streams and copies them out (reset != 0: and zeroes them); unet_counters_sum adds up the counters of several
+ * contexts, e.g. one per GPU of this process.  Across processes (one rank per GPU) the 256 bytes are summed by
+ * the job's own collective: an RCCL all-reduce, or the launcher's. */
+int unet_counters(unet_ctx* ctx, uint64_t* out /* UNET_V_COUNT */, int reset);
+int unet_counters_sum(unet_ctx* const* ctxs, uint32_t n_ctx, uint64_t* out /* UNET_V_COUNT */, int reset);
 
 /* --------------------------------------------------- flow-hash sharding */
 /* Build-defined 32-bit mix of the 5-tuple (ports are 0 unless protocol is UDP, or TCP

@@ -85,6 +85,70 @@ __global__ __launch_bounds__(256) void k_copy_wave4k(const u32x4* __restrict__ s
     }
 }
 
+// One piece of P KiB per wave and nothing else: grid = pieces / (block / 64).  All loads, then all stores.
+template <int P, int LD, int ST>
+__global__ __launch_bounds__(256) void k_copy_piece(const u32x4* __restrict__ src, u32x4* __restrict__ dst, u64 n) {
+    const u32 lane = threadIdx.x & 63u;
+    const u64 piece = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const u64 at = piece * (u64)(P * 64) + lane;
+    if (at - lane + P * 64 > n) return;
+    u32x4 v[P];
+#pragma unroll
+    for (int k = 0; k < P; k++) v[k] = (LD & 2) ? __builtin_nontemporal_load(src + at + k * 64) : src[at + k * 64];
+#pragma unroll
+    for (int k = 0; k < P; k++) {
+        if (ST & 2) __builtin_nontemporal_store(v[k], dst + at + k * 64);
+        else dst[at + k * 64] = v[k];
+    }
+}
+
+// Piece of P KiB per wave, loop of `reps` pieces per wave with the next piece's loads issued before the current
+// piece's stores (two register sets): what a pipelined packet builder would do.
+template <int P, int LD, int ST>
+__global__ __launch_bounds__(256) void k_copy_piece_pipe(const u32x4* __restrict__ src, u32x4* __restrict__ dst, u64 n, u32 reps) {
+    const u32 lane = threadIdx.x & 63u;
+    const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    u64 at = wave * reps * (u64)(P * 64) + lane;
+    u32x4 a[P], b[P];
+    if (at - lane + P * 64 > n) return;
+#pragma unroll
+    for (int k = 0; k < P; k++) a[k] = (LD & 2) ? __builtin_nontemporal_load(src + at + k * 64) : src[at + k * 64];
+    for (u32 r = 0; r < reps; r++) {
+        const u64 nx = at + P * 64;
+        const bool more = r + 1 < reps && nx - lane + P * 64 <= n;
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < P; k++) b[k] = (LD & 2) ? __builtin_nontemporal_load(src + nx + k * 64) : src[nx + k * 64];
+        }
+#pragma unroll
+        for (int k = 0; k < P; k++) {
+            if (ST & 2) __builtin_nontemporal_store(a[k], dst + at + k * 64);
+            else dst[at + k * 64] = a[k];
+        }
+        if (!more) break;
+#pragma unroll
+        for (int k = 0; k < P; k++) a[k] = b[k];
+        at = nx;
+    }
+}
+
+// One table-described record per wave, the way a packet builder meets its input: wave w reads off[w], len[w]
+// and out_off[w] (wave-uniform, so scalar loads), copies the record's chunks with two clamped 1 KiB row loads
+// and stores them 28 bytes further (header room), i.e. through a one-lane shift like the real kernel.
+__global__ __launch_bounds__(256) void k_copy_record_wave(const u32x4* __restrict__ src, u32x4* __restrict__ dst, const u32* __restrict__ off,
+                                                          const u32* __restrict__ len, const u32* __restrict__ out_off, u32 n) {
+    const u32 lane = threadIdx.x & 63u;
+    const u32 w = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (w >= n) return;
+    const u32 l = len[w], nch = (l + 15u) >> 4, last = nch - 1u;
+    const u32x4* p = src + off[w];
+    u32x4* q = dst + out_off[w];
+    const u32x4 a = __builtin_nontemporal_load(p + min(lane, last));
+    const u32x4 b = __builtin_nontemporal_load(p + min(lane + 64u, last));
+    if (lane < nch) __builtin_nontemporal_store(a, q + lane);
+    if (lane + 64u < nch) __builtin_nontemporal_store(b, q + lane + 64u);
+}
+
 template <int ST>
 __global__ __launch_bounds__(256) void k_fill(uint8_t* __restrict__ dst, u64 nchunks) {
     const u64 per = ((nchunks + gridDim.x - 1) / gridDim.x + 255u) & ~255ull;
@@ -152,6 +216,32 @@ int main(int argc, char** argv) {
         REPORT("wave per 4 KiB piece ld2 st0", grid, 256, ms);
         ms = timeit([&] { hipLaunchKernelGGL((k_copy_wave4k<0, 0>), dim3(grid), dim3(256), 0, 0, (const u32x4*)s, (u32x4*)d, n); }, 6);
         REPORT("wave per 4 KiB piece ld0 st0", grid, 256, ms);
+    }
+#define PIECE(P, LD, ST, block) { const u64 pieces = n / (P * 64); const int grid = (int)((pieces + (block / 64) - 1) / (block / 64)); \
+        double ms = timeit([&] { hipLaunchKernelGGL((k_copy_piece<P, LD, ST>), dim3(grid), dim3(block), 0, 0, (const u32x4*)s, (u32x4*)d, n); }, 6); \
+        REPORT("one " #P " KiB piece per wave ld" #LD " st" #ST, grid, block, ms); }
+    PIECE(1, 2, 2, 256) PIECE(2, 2, 2, 256) PIECE(4, 2, 2, 256) PIECE(8, 2, 2, 256) PIECE(16, 2, 2, 256)
+    PIECE(1, 2, 2, 64) PIECE(4, 2, 2, 64) PIECE(8, 2, 2, 64)
+    PIECE(4, 0, 0, 256) PIECE(4, 2, 0, 256) PIECE(4, 0, 2, 256) PIECE(8, 0, 0, 256) PIECE(8, 2, 0, 256)
+#define PIPE(P, LD, ST, reps) { const u64 pieces = n / (P * 64); const int grid = (int)((pieces / reps + 3) / 4); \
+        double ms = timeit([&] { hipLaunchKernelGGL((k_copy_piece_pipe<P, LD, ST>), dim3(grid), dim3(256), 0, 0, (const u32x4*)s, (u32x4*)d, n, (u32)reps); }, 6); \
+        REPORT("pipelined " #P " KiB pieces x" #reps " ld" #LD " st" #ST, grid, 256, ms); }
+    PIPE(2, 2, 2, 4) PIPE(2, 2, 2, 16) PIPE(4, 2, 2, 2) PIPE(4, 2, 2, 4) PIPE(4, 2, 2, 8) PIPE(4, 2, 2, 16) PIPE(8, 2, 2, 4) PIPE(8, 2, 2, 16)
+    PIPE(4, 2, 0, 4) PIPE(4, 0, 0, 4)
+    {
+        // 1504-byte records (94 chunks) packed back to back, described by tables
+        const u32 nrec = (u32)(n / 94);
+        u32 *h = (u32*)malloc(3ull * nrec * 4), *dt;
+        for (u32 i = 0; i < nrec; i++) { h[i] = i * 94u; h[nrec + i] = 1500u; h[2 * nrec + i] = i * 94u; }
+        CK(hipMalloc(&dt, 3ull * nrec * 4));
+        CK(hipMemcpy(dt, h, 3ull * nrec * 4, hipMemcpyHostToDevice));
+        for (int block : {64, 128, 256}) {
+            const int grid = (int)((nrec + block / 64 - 1) / (block / 64));
+            double ms = timeit([&] { hipLaunchKernelGGL(k_copy_record_wave, dim3(grid), dim3(block), 0, 0, (const u32x4*)s, (u32x4*)d, dt, dt + nrec, dt + 2 * nrec, nrec); }, 6);
+            printf("%-34s grid %6d block %4d : %7.3f ms  %7.1f GB/s\n", "one 1500-B record per wave, tables", grid, block, ms, 2.0 * nrec * 1504.0 / ms / 1e6);
+        }
+        CK(hipFree(dt));
+        free(h);
     }
     // write only (GB/s here = written bytes * 2 / time, halve it)
     {

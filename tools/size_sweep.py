@@ -15,7 +15,8 @@ ctx = unet_amd.Offload(0)
 st = torch.cuda.Stream()
 torch.cuda.set_stream(st)
 ifc = unet_amd.Iface(ext_tcp=True)
-total = 4 << 30
+total = int(os.environ.get("UNET_SWEEP_TOTAL", 4 << 30))
+iters = int(os.environ.get("UNET_SWEEP_ITERS", 10))
 buf = torch.randint(0, 2**31 - 1, (total // 4 + 16,), dtype=torch.int32, device="cuda").view(torch.uint8)
 out = []
 for L in sizes:
@@ -31,15 +32,15 @@ for L in sizes:
                 ctx.verify_dev(buf.data_ptr(), nbytes, None, slots, d_len.data_ptr(), n, ifc, d_out.data_ptr(), st.cuda_stream)
             else:
                 ctx.csum_batch_dev(buf.data_ptr(), nbytes, None, slots, d_len.data_ptr(), None, n, d_out.data_ptr(), st.cuda_stream)
-        for _ in range(3):
+        for _ in range(2):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(10):
+        for _ in range(iters):
             run()
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 10
+        ms = e0.elapsed_time(e1) / iters
         row[name + "_GBps"] = round(n * (L + 8) / ms / 1e6, 1)
         row[name + "_Gpkt_s"] = round(n / ms / 1e6, 3)
     out.append(row)

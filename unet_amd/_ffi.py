@@ -143,6 +143,10 @@ _SIGS = {
     "unet_ipv4_validate": (C.c_int, [_vp, _u8p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
     "unet_verify_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
     "unet_verify": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
+    "unet_verify_async": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp, C.POINTER(C.c_uint32)]),
+    "unet_wait": (C.c_int, [_vp, C.c_uint32]),
+    "unet_counters": (C.c_int, [_vp, _u64p, C.c_int]),
+    "unet_counters_sum": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, _u64p, C.c_int]),
     "unet_verify_static": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
     "unet_hint_mean_len": (C.c_int, [_vp, C.c_uint32]),
     "unet_generate_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, _u8p]),
@@ -428,6 +432,25 @@ class Offload:
         ic = iface.c()
         _check(self.lib.unet_verify_static(self.h, _np_ptr(arena), arena.nbytes, _np_ptr(off16), stride16, _np_ptr(lens), n,
                                            C.byref(ic), _np_ptr(out)))
+        return out
+
+    def verify_async(self, arena: np.ndarray, off16, lens: np.ndarray, iface: Iface, stride16: int = 0):
+        """unet_verify_async -> (ticket, out): `out` holds the results once wait(ticket) has returned."""
+        arena, off16, lens = self._prep(arena, off16, lens)
+        n = len(lens)
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        ic = iface.c()
+        t = C.c_uint32(0)
+        _check(self.lib.unet_verify_async(self.h, _np_ptr(arena), arena.nbytes, _np_ptr(off16), stride16, _np_ptr(lens), n,
+                                          C.byref(ic), _np_ptr(out), C.byref(t)))
+        return int(t.value), out
+
+    def wait(self, ticket: int):
+        _check(self.lib.unet_wait(self.h, ticket))
+
+    def counters(self, reset: bool = False) -> np.ndarray:
+        out = np.zeros(V_COUNT, dtype=np.uint64)
+        _check(self.lib.unet_counters(self.h, _np_ptr(out), 1 if reset else 0))
         return out
 
     def hint_mean_len(self, mean_len: int):

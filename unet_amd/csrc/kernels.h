@@ -27,8 +27,11 @@ struct Batch {
 #ifndef UNET_MID_PATH
 #define UNET_MID_PATH 1       // tile_sums: lane groups for records of 81..1024 bytes
 #endif
+#ifndef UNET_OCC64
+#define UNET_OCC64 5          // workgroups per CU of the 64-record-tile kernels (their LDS allows 5)
+#endif
 #ifndef UNET_SPAN_PATH
-#define UNET_SPAN_PATH 0      // tile_sums: tiles of short records staged in LDS as one coalesced byte range
+#define UNET_SPAN_PATH 1      // tile_sums: tiles of short records staged in LDS as one coalesced byte range
 #endif
 #ifndef UNET_TX_SMALL_PATH
 #define UNET_TX_SMALL_PATH 1  // k_tx_build: one lane per packet up to 48-byte payloads
@@ -80,7 +83,10 @@ constexpr u32 kSmallChunks = UNET_SMALL_CHUNKS;  // records of up to this many c
 constexpr u32 kHdrChunks = 6;     // 96 bytes: 14 (Ethernet) + 60 (max IPv4 header) + 16 (deepest L4 field) = 90
 // + the record's partial last chunk.  7 chunks = 28 dwords: lanes writing the same chunk of their own
 // records spread over the LDS banks (a power-of-two stride would put them all on the same few).
-constexpr u32 kLdsChunksPerRec = kHdrChunks + 1;
+#ifndef UNET_LDS_PER_REC
+#define UNET_LDS_PER_REC (kHdrChunks + 1)  // (smaller values only for occupancy experiments on uniform short records)
+#endif
+constexpr u32 kLdsChunksPerRec = UNET_LDS_PER_REC;
 constexpr u32 kRow4Chunks = UNET_ROW4_CHUNKS;  // longer records up to 16 chunks (256 bytes) are handled by 4 lanes,
 constexpr u32 kRow8Chunks = 32;   // up to 32 chunks (512 bytes) by 8 lanes,
 constexpr u32 kMidChunks = 64;    // up to 64 chunks (1024 bytes) by a 16-lane row
@@ -571,7 +577,7 @@ __device__ __forceinline__ u32 tile_sums(const Batch& b, Tile& t, u32x4* __restr
 // ---------------------------------------------------------------- a1: calculate_checksum
 // out[i] = calculate_checksum(record i, seeds[i])  (src/utils.rs:1-17)
 template <int TILE>
-__global__ __launch_bounds__(kBlock, TILE == 64 ? 5 : 6) void k_csum(Batch b, const uint16_t* __restrict__ seeds,
+__global__ __launch_bounds__(kBlock, TILE == 64 ? UNET_OCC64 : 6) void k_csum(Batch b, const uint16_t* __restrict__ seeds,
                                                     uint16_t* __restrict__ out) {
     static_assert(TILE >= 1 && TILE <= 64, "one lane per record of the tile");
     UNET_TILE_LDS(TILE);
@@ -587,7 +593,7 @@ __global__ __launch_bounds__(kBlock, TILE == 64 ? 5 : 6) void k_csum(Batch b, co
 
 // ------------------------------------------- a2-a6, a8, a11: receive-path verdicts
 template <int MODE, int TILE>
-__global__ __launch_bounds__(kBlock, TILE == 64 ? 5 : 6) void k_verify(Batch b, IfaceDev ifc, u32* __restrict__ out) {
+__global__ __launch_bounds__(kBlock, TILE == 64 ? UNET_OCC64 : 6) void k_verify(Batch b, IfaceDev ifc, u32* __restrict__ out) {
     static_assert(TILE >= 1 && TILE <= 64, "one lane per record of the tile");
     UNET_TILE_LDS(TILE);
     Tile t;
@@ -675,7 +681,7 @@ __global__ __launch_bounds__(kBlock) void k_ipv4_validate_rows(const u32x4* __re
 // IN_PLACE = false leaves the packets alone and writes the two values to fields[i] = ip_csum | l4_csum << 16
 // instead (0 for a record that is not filled): a pure read pass.
 template <int TILE, bool IN_PLACE>
-__global__ __launch_bounds__(kBlock, TILE == 64 ? 5 : 6) void k_generate(Batch b, uint8_t* __restrict__ arena_rw,
+__global__ __launch_bounds__(kBlock, TILE == 64 ? UNET_OCC64 : 6) void k_generate(Batch b, uint8_t* __restrict__ arena_rw,
                                                         u32* __restrict__ fields, uint8_t* __restrict__ status) {
     static_assert(TILE >= 1 && TILE <= 64, "one lane per record of the tile");
     UNET_TILE_LDS(TILE);
@@ -1040,8 +1046,11 @@ __device__ __forceinline__ void tx_rows_path(const Batch& pay, const Tile& t, bo
 // Lane j first prepares packet j's headers (every field and the IPv4 checksum; the L4 checksum as a
 // partial sum) and parks them in LDS; the wave then builds the packets one after another, reading each
 // payload once and writing each packet once, in whole 1 KiB rows from its first byte.
+#ifndef UNET_TX_OCC
+#define UNET_TX_OCC 1   // workgroups per CU the register allocator must leave room for
+#endif
 template <int MODE, int TILE>
-__global__ __launch_bounds__(kBlock) void k_tx_build(Batch pay, const TxDesc* __restrict__ desc, IfaceDev ifc,
+__global__ __launch_bounds__(kBlock, UNET_TX_OCC) void k_tx_build(Batch pay, const TxDesc* __restrict__ desc, IfaceDev ifc,
                                                      uint8_t* __restrict__ out_arena, u64 out_bytes,
                                                      const u32* __restrict__ out_off16, u32* __restrict__ out_len,
                                                      uint8_t* __restrict__ status) {

@@ -20,7 +20,19 @@
 
 using namespace unetdev;
 
+#include <cstddef>
+// Layouts other languages bind to (rust/unet-offload-sys mirrors them as #[repr(C)] structs).
 static_assert(sizeof(unet_result) == 4, "unet_result must stay 4 bytes");
+static_assert(offsetof(unet_result, csum) == 0 && offsetof(unet_result, verdict) == 2 && offsetof(unet_result, proto) == 3, "unet_result layout");
+static_assert(sizeof(unet_iface) == 16, "unet_iface layout");
+static_assert(offsetof(unet_iface, broadcast) == 4 && offsetof(unet_iface, mac) == 8 && offsetof(unet_iface, mode) == 14 && offsetof(unet_iface, ext_tcp) == 15, "unet_iface layout");
+static_assert(sizeof(unet_tx_desc) == 28, "unet_tx_desc layout");
+static_assert(offsetof(unet_tx_desc, dst) == 4 && offsetof(unet_tx_desc, l4a) == 8 && offsetof(unet_tx_desc, l4b) == 10 && offsetof(unet_tx_desc, values) == 12 &&
+              offsetof(unet_tx_desc, ip_id) == 16 && offsetof(unet_tx_desc, proto) == 18 && offsetof(unet_tx_desc, dst_mac) == 20, "unet_tx_desc layout");
+static_assert(sizeof(unet_tx_fields) == 4 && offsetof(unet_tx_fields, l4_csum) == 2, "unet_tx_fields layout");
+static_assert(sizeof(unet_pcap_info) == 48 && offsetof(unet_pcap_info, nanosecond) == 28 && offsetof(unet_pcap_info, arena_bytes) == 32 &&
+              offsetof(unet_pcap_info, trailing_bytes) == 40, "unet_pcap_info layout");
+static_assert(sizeof(unet_ticket) == 4, "unet_ticket layout");
 static_assert((int)UNET_V_COUNT == (int)V_COUNT, "verdict tables out of sync");
 static_assert((int)UNET_V_L3_HEADER_OK == (int)V_L3_HEADER_OK, "verdict tables out of sync");
 static_assert((int)UNET_V_ACCEPT_UDP == (int)V_ACCEPT_UDP, "verdict tables out of sync");
@@ -164,9 +176,24 @@ struct unet_ctx {
     DevBuf d_arena, d_off, d_len, d_out, d_aux, d_tx, d_tx_tab;
     CopyPool* pool = nullptr;
     int tile_override = 0;        // UNET_TILE, read once at unet_open
+    int tx_tile_override = 0;     // UNET_TX_TILE (4, 8, 16, 32, 64), read once at unet_open
     bool hdr_plain = false;       // UNET_HDR_PLAIN, read once at unet_open
     u32 mean_len_hint = 0;        // unet_hint_mean_len
     uint8_t* scratch_dev = nullptr;  // this device's copy of the static scratch array
+    unsigned long long* d_counts = nullptr;  // UNET_V_COUNT per-verdict counters of the host-pointer entry points
+    hipEvent_t results_ready = nullptr;
+    // unet_verify_async: batches in flight, each with its own stream, pinned image and device image
+    struct AsyncSlot {
+        hipStream_t s = nullptr;
+        hipEvent_t done = nullptr;
+        void* pin = nullptr;
+        size_t pin_cap = 0;
+        DevBuf dev;
+        bool busy = false;
+        u32 seq = 0, n = 0;
+        size_t res_at = 0;
+        unet_result* out = nullptr;
+    } slot[UNET_ASYNC_DEPTH];
 };
 
 namespace {
@@ -312,6 +339,51 @@ struct MeanScope {
     ~MeanScope() { c->mean_len_hint = old; }
 };
 
+// One batch as a single staging image [len | off16 | arena bytes that hold records]: one host-to-device copy.
+struct Image {
+    u64 at_off, at_arena, used, total, sum_len;
+};
+
+int plan_image(uint64_t arena_bytes, const uint32_t* off16, uint32_t stride16, const uint32_t* len, uint32_t n, Image* im) {
+    u64 used = 16, sum_len = 0;
+    for (u32 i = 0; i < n; i++) {
+        if (len[i] > kMaxLen) return fail(UNET_E_RANGE, "record %u: length %u > 65535", i, len[i]);
+        const u64 slot = off16 ? off16[i] : (u64)i * stride16;
+        if (slot > 0xffffffffull) return fail(UNET_E_RANGE, "record %u starts past 2^32 16-byte slots", i);
+        const u64 end = slot * 16u + (((u64)len[i] + 15u) & ~15ull);
+        if (end > arena_bytes) return fail(UNET_E_RANGE, "record %u ends at byte %llu, arena is %llu bytes (records are read in 16-byte chunks)", i, (unsigned long long)end, (unsigned long long)arena_bytes);
+        if (end > used) used = end;
+        sum_len += len[i];
+    }
+    const u64 tab = ((u64)n * 4u + 15u) & ~15ull;
+    im->at_off = tab;
+    im->at_arena = off16 ? 2u * tab : tab;
+    im->used = used;
+    im->total = im->at_arena + used;
+    im->sum_len = sum_len;
+    return UNET_OK;
+}
+
+void fill_image(unet_ctx* c, uint8_t* pin, const Image& im, const uint8_t* arena, const uint32_t* off16, const uint32_t* len, uint32_t n) {
+    memcpy(pin, len, (size_t)n * 4u);
+    if (off16) memcpy(pin + im.at_off, off16, (size_t)n * 4u);
+    c->pool->copy(pin + im.at_arena, arena, im.used);
+}
+
+Batch image_batch(const uint8_t* dev, const Image& im, bool has_off, uint32_t stride16, uint32_t n) {
+    return Batch{dev + im.at_arena, im.used, has_off ? (const u32*)(dev + im.at_off) : nullptr, stride16, (const u32*)dev, n};
+}
+
+// Adds the verdicts of n results to the context's own counters (device-resident, read by unet_counters).
+int count_into_ctx(unet_ctx* c, hipStream_t s, const u32* d_results, u32 n) {
+    if (n == 0) return UNET_OK;
+    u32 grid = (n + kBlock - 1) / kBlock;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_count_verdicts, dim3(grid), dim3(kBlock), 0, s, d_results, n, c->d_counts);
+    HIP_TRY(hipGetLastError());
+    return UNET_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -348,6 +420,13 @@ int unet_open(int device_id, unet_ctx** out_ctx) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->pinned_free[i], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->copied, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->results_ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_counts, UNET_V_COUNT * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(c->d_counts, 0, UNET_V_COUNT * sizeof(unsigned long long));
+    for (int i = 0; i < UNET_ASYNC_DEPTH && e == hipSuccess; i++) {
+        e = hipStreamCreateWithFlags(&c->slot[i].s, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->slot[i].done, hipEventDisableTiming);
+    }
     if (e != hipSuccess) {
         fail(UNET_E_HIP, "context setup failed: %s", hipGetErrorString(e));
         unet_close(c);
@@ -376,6 +455,10 @@ int unet_open(int device_id, unet_ctx** out_ctx) {
         c->tile_override = v <= 16 ? 16 : (v <= 32 ? 32 : 64);
     }
     c->hdr_plain = getenv("UNET_HDR_PLAIN") != nullptr;
+    if (const char* t = getenv("UNET_TX_TILE")) {
+        const int v = atoi(t);
+        c->tx_tile_override = v <= 4 ? 4 : (v <= 8 ? 8 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)));
+    }
     int rc = static_scratch_of(device_id, &c->scratch_dev);
     if (rc) {
         unet_close(c);
@@ -398,6 +481,15 @@ void unet_close(unet_ctx* c) {
         if (c->pinned_free[i]) (void)hipEventDestroy(c->pinned_free[i]);
     }
     delete c->pool;
+    for (auto& sl : c->slot) {
+        if (sl.s) (void)hipStreamSynchronize(sl.s);
+        if (sl.pin) (void)hipHostFree(sl.pin);
+        if (sl.dev.p) (void)hipFree(sl.dev.p);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.s) (void)hipStreamDestroy(sl.s);
+    }
+    if (c->d_counts) (void)hipFree(c->d_counts);
+    if (c->results_ready) (void)hipEventDestroy(c->results_ready);
     if (c->copied) (void)hipEventDestroy(c->copied);
     if (c->s_comp) (void)hipStreamDestroy(c->s_comp);
     if (c->s_copy) (void)hipStreamDestroy(c->s_copy);
@@ -409,6 +501,7 @@ int unet_sync(unet_ctx* c) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->s_copy));
     HIP_TRY(hipStreamSynchronize(c->s_comp));
+    for (auto& sl : c->slot) HIP_TRY(hipStreamSynchronize(sl.s));
     return UNET_OK;
 }
 
@@ -524,6 +617,7 @@ int unet_ipv4_validate(unet_ctx* c, const uint8_t* hdrs, uint32_t n, const unet_
     if ((rc = h2d(c, c->d_arena.p, hdrs, bytes))) return rc;
     if ((rc = copies_before_compute(c))) return rc;
     if ((rc = unet_ipv4_validate_dev(c, nullptr, (const uint8_t*)c->d_arena.p, n, iface, (unet_result*)c->d_out.p))) return rc;
+    if ((rc = count_into_ctx(c, c->s_comp, (const u32*)c->d_out.p, n))) return rc;
     return d2h_sync(c, out, c->d_out.p, (size_t)n * 4);
 }
 
@@ -550,16 +644,100 @@ int unet_verify(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const u
     if (n == 0) return UNET_OK;
     if (!arena || !len || !iface || !out) return fail(UNET_E_INVAL, "null argument");
     if (!off16 && stride16 == 0) return fail(UNET_E_INVAL, "need an offset table or a non-zero stride");
+    if (iface->mode != UNET_MODE_L3 && iface->mode != UNET_MODE_L2) return fail(UNET_E_INVAL, "bad iface mode %d", iface->mode);
     HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if (arena_bytes + 2ull * n * 4u + 32u <= kStageBytes && (u64)n * 4u <= kStageBytes) {
+        // small batch (a drained protocol queue): one staging image, one copy each way, everything on one stream
+        Image im;
+        if ((rc = plan_image(arena_bytes, off16, stride16, len, n, &im))) return rc;
+        const u64 res_at = (im.total + 255u) & ~255ull;
+        if ((rc = ensure(c, c->d_arena, res_at + (u64)n * 4u))) return rc;
+        HIP_TRY(hipEventSynchronize(c->pinned_free[0]));
+        HIP_TRY(hipEventSynchronize(c->pinned_free[1]));
+        fill_image(c, (uint8_t*)c->pinned[0], im, arena, off16, len, n);
+        uint8_t* dev = (uint8_t*)c->d_arena.p;
+        HIP_TRY(hipMemcpyAsync(dev, c->pinned[0], im.total, hipMemcpyHostToDevice, c->s_comp));
+        u32* d_out = (u32*)(dev + res_at);
+        const int tile = c->tile_override ? c->tile_override : tile_for_mean(im.sum_len / n);
+        if ((rc = launch_verify(c->s_comp, image_batch(dev, im, off16 != nullptr, stride16, n), iface, tile, d_out))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->pinned[1], d_out, (size_t)n * 4u, hipMemcpyDeviceToHost, c->s_comp));
+        HIP_TRY(hipEventRecord(c->results_ready, c->s_comp));
+        if ((rc = count_into_ctx(c, c->s_comp, d_out, n))) return rc;
+        HIP_TRY(hipEventSynchronize(c->results_ready));
+        memcpy(out, c->pinned[1], (size_t)n * 4u);
+        return UNET_OK;
+    }
     Batch b;
     u32 mean = 0;
-    int rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b, &mean);
+    rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b, &mean);
     MeanScope hint(c, mean);
     if (rc) return rc;
     if ((rc = ensure(c, c->d_out, (size_t)n * 4))) return rc;
     rc = unet_verify_dev(c, nullptr, b.arena, b.arena_bytes, b.off16, b.stride16, b.len, n, iface, (unet_result*)c->d_out.p);
     if (rc) return rc;
+    if ((rc = count_into_ctx(c, c->s_comp, (const u32*)c->d_out.p, n))) return rc;
     return d2h_sync(c, out, c->d_out.p, (size_t)n * 4);
+}
+
+int unet_verify_async(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16, uint32_t stride16,
+                      const uint32_t* len, uint32_t n, const unet_iface* iface, unet_result* out, unet_ticket* ticket) {
+    if (!c || !ticket) return fail(UNET_E_INVAL, "null context or ticket");
+    ticket->id = UNET_TICKET_NONE;
+    if (n == 0) return UNET_OK;
+    if (!arena || !len || !iface || !out) return fail(UNET_E_INVAL, "null argument");
+    if (!off16 && stride16 == 0) return fail(UNET_E_INVAL, "need an offset table or a non-zero stride");
+    if (iface->mode != UNET_MODE_L3 && iface->mode != UNET_MODE_L2) return fail(UNET_E_INVAL, "bad iface mode %d", iface->mode);
+    int k = -1;
+    for (int i = 0; i < UNET_ASYNC_DEPTH; i++)
+        if (!c->slot[i].busy) { k = i; break; }
+    if (k < 0) return fail(UNET_E_BUSY, "%d batches are already in flight: unet_wait for one first", UNET_ASYNC_DEPTH);
+    unet_ctx::AsyncSlot& sl = c->slot[k];
+    HIP_TRY(hipSetDevice(c->device));
+    Image im;
+    int rc = plan_image(arena_bytes, off16, stride16, len, n, &im);
+    if (rc) return rc;
+    const u64 res_at = (im.total + 255u) & ~255ull, need = res_at + (u64)n * 4u;
+    if (need > sl.pin_cap) {
+        if (sl.pin) HIP_TRY(hipHostFree(sl.pin));
+        sl.pin = nullptr;
+        sl.pin_cap = 0;
+        const size_t want = (need + (1u << 20) - 1) & ~((size_t)(1u << 20) - 1);
+        hipError_t e = hipHostMalloc(&sl.pin, want, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(UNET_E_NOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        sl.pin_cap = want;
+    }
+    if ((rc = ensure(c, sl.dev, need))) return rc;
+    // the caller's buffers are free again when this returns: everything the GPU reads sits in the pinned image
+    fill_image(c, (uint8_t*)sl.pin, im, arena, off16, len, n);
+    uint8_t* dev = (uint8_t*)sl.dev.p;
+    HIP_TRY(hipMemcpyAsync(dev, sl.pin, im.total, hipMemcpyHostToDevice, sl.s));
+    u32* d_out = (u32*)(dev + res_at);
+    const int tile = c->tile_override ? c->tile_override : tile_for_mean(im.sum_len / n);
+    if ((rc = launch_verify(sl.s, image_batch(dev, im, off16 != nullptr, stride16, n), iface, tile, d_out))) return rc;
+    HIP_TRY(hipMemcpyAsync((uint8_t*)sl.pin + res_at, d_out, (size_t)n * 4u, hipMemcpyDeviceToHost, sl.s));
+    HIP_TRY(hipEventRecord(sl.done, sl.s));
+    if ((rc = count_into_ctx(c, sl.s, d_out, n))) return rc;
+    sl.busy = true;
+    sl.seq = (sl.seq + 1u) & 0xffffffu;
+    sl.n = n;
+    sl.res_at = res_at;
+    sl.out = out;
+    ticket->id = (u32)k | (sl.seq << 8);
+    return UNET_OK;
+}
+
+int unet_wait(unet_ctx* c, unet_ticket ticket) {
+    if (!c) return fail(UNET_E_INVAL, "null context");
+    if (ticket.id == UNET_TICKET_NONE) return UNET_OK;  // an empty batch
+    const u32 k = ticket.id & 0xffu;
+    if (k >= UNET_ASYNC_DEPTH || !c->slot[k].busy || c->slot[k].seq != (ticket.id >> 8)) return fail(UNET_E_INVAL, "ticket %u is not in flight", ticket.id);
+    unet_ctx::AsyncSlot& sl = c->slot[k];
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(sl.done));
+    memcpy(sl.out, (const uint8_t*)sl.pin + sl.res_at, (size_t)sl.n * 4u);
+    sl.busy = false;
+    return UNET_OK;
 }
 
 // No counterpart in the reference: unet_verify for callers that cannot allocate.  Same kernel; the device-side
@@ -576,37 +754,26 @@ int unet_verify_static(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, 
     if (n > kStaticMaxRecords)
         return fail(UNET_E_RANGE, "unet_verify_static takes at most %u records per call, got %u (use unet_verify)", kStaticMaxRecords, n);
     // the records, wherever they sit in the caller's arena, must end inside its first kStaticMaxArena bytes
-    u64 used = 16, sum_len = 0;
-    for (u32 i = 0; i < n; i++) {
-        if (len[i] > kMaxLen) return fail(UNET_E_RANGE, "record %u: length %u > 65535", i, len[i]);
-        const u64 slot = off16 ? off16[i] : (u64)i * stride16;
-        const u64 end = slot * 16u + (((u64)len[i] + 15u) & ~15ull);
-        if (end > arena_bytes) return fail(UNET_E_RANGE, "record %u ends at byte %llu, arena is %llu bytes (records are read in 16-byte chunks)", i, (unsigned long long)end, (unsigned long long)arena_bytes);
-        if (end > used) used = end;
-        sum_len += len[i];
-    }
-    if (used > kStaticMaxArena)
+    Image im;
+    int rc = plan_image(arena_bytes, off16, stride16, len, n, &im);
+    if (rc) return rc;
+    if (im.used > kStaticMaxArena)
         return fail(UNET_E_RANGE, "unet_verify_static takes records inside the arena's first %llu bytes, these reach byte %llu (use unet_verify)",
-                    (unsigned long long)kStaticMaxArena, (unsigned long long)used);
+                    (unsigned long long)kStaticMaxArena, (unsigned long long)im.used);
     HIP_TRY(hipSetDevice(c->device));
     // one staging image [len | off16 | arena], one H2D copy, one launch, one D2H copy, all on the compute stream
-    const u64 tab = ((u64)n * 4u + 15u) & ~15ull;
-    const u64 at_off = tab, at_arena = off16 ? 2u * tab : tab;
     HIP_TRY(hipEventSynchronize(c->pinned_free[0]));
     HIP_TRY(hipEventSynchronize(c->pinned_free[1]));
-    uint8_t* pin = (uint8_t*)c->pinned[0];
-    memcpy(pin, len, (size_t)n * 4u);
-    if (off16) memcpy(pin + at_off, off16, (size_t)n * 4u);
-    memcpy(pin + at_arena, arena, used);
+    fill_image(c, (uint8_t*)c->pinned[0], im, arena, off16, len, n);
     uint8_t* dev = c->scratch_dev;  // never the array's name: that is not a device address in host code
-    HIP_TRY(hipMemcpyAsync(dev, pin, at_arena + used, hipMemcpyHostToDevice, c->s_comp));
-    Batch b{dev + at_arena, used, off16 ? (const u32*)(dev + at_off) : nullptr, stride16, (const u32*)dev, n};
+    HIP_TRY(hipMemcpyAsync(dev, c->pinned[0], im.total, hipMemcpyHostToDevice, c->s_comp));
     u32* d_out = (u32*)(dev + kStaticOutAt);
-    const int tile = c->tile_override ? c->tile_override : tile_for_mean(sum_len / n);
-    int rc = launch_verify(c->s_comp, b, iface, tile, d_out);
-    if (rc) return rc;
+    const int tile = c->tile_override ? c->tile_override : tile_for_mean(im.sum_len / n);
+    if ((rc = launch_verify(c->s_comp, image_batch(dev, im, off16 != nullptr, stride16, n), iface, tile, d_out))) return rc;
     HIP_TRY(hipMemcpyAsync(c->pinned[1], d_out, (size_t)n * 4u, hipMemcpyDeviceToHost, c->s_comp));
-    HIP_TRY(hipStreamSynchronize(c->s_comp));
+    HIP_TRY(hipEventRecord(c->results_ready, c->s_comp));
+    if ((rc = count_into_ctx(c, c->s_comp, d_out, n))) return rc;
+    HIP_TRY(hipEventSynchronize(c->results_ready));
     memcpy(out, c->pinned[1], (size_t)n * 4u);
     return UNET_OK;
 }
@@ -709,13 +876,17 @@ int unet_tx_build_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload_aren
 #define UNET_TX_LAUNCH(M, T)                                                                                             \
     hipLaunchKernelGGL((k_tx_build<M, T>), dim3(tiles_grid(n, T)), dim3(kBlock), 0, pick(ctx, stream), b, (const TxDesc*)d_desc, ifc, \
                        d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status)
-    const int tile = pick_tile(ctx, payload_arena_bytes, payload_stride16, n);
+    int tile = pick_tile(ctx, payload_arena_bytes, payload_stride16, n);
+    if (ctx->tx_tile_override) tile = ctx->tx_tile_override;
     if (iface->mode == UNET_MODE_L2) {
-        if (tile == 16) UNET_TX_LAUNCH(MODE_L2, 16);
+        if (tile == 8) UNET_TX_LAUNCH(MODE_L2, 8);
+        else if (tile == 16) UNET_TX_LAUNCH(MODE_L2, 16);
         else if (tile == 32) UNET_TX_LAUNCH(MODE_L2, 32);
         else UNET_TX_LAUNCH(MODE_L2, 64);
     } else {
-        if (tile == 16) UNET_TX_LAUNCH(MODE_L3, 16);
+        if (tile == 4) UNET_TX_LAUNCH(MODE_L3, 4);
+        else if (tile == 8) UNET_TX_LAUNCH(MODE_L3, 8);
+        else if (tile == 16) UNET_TX_LAUNCH(MODE_L3, 16);
         else if (tile == 32) UNET_TX_LAUNCH(MODE_L3, 32);
         else UNET_TX_LAUNCH(MODE_L3, 64);
     }
@@ -780,13 +951,37 @@ int unet_tx_build(unet_ctx* c, const uint8_t* payload_arena, uint64_t payload_ar
 int unet_count_verdicts_dev(unet_ctx* ctx, void* stream, const unet_result* d_results, uint32_t n, uint64_t* d_counts) {
     if (!ctx) return fail(UNET_E_INVAL, "null context");
     if (n == 0) return UNET_OK;
-    if (!d_results || !d_counts) return fail(UNET_E_INVAL, "null argument");
+    if (!d_results) return fail(UNET_E_INVAL, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
     u32 grid = (n + kBlock - 1) / kBlock;
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(k_count_verdicts, dim3(grid), dim3(kBlock), 0, pick(ctx, stream), (const u32*)d_results, n,
-                       (unsigned long long*)d_counts);
+                       d_counts ? (unsigned long long*)d_counts : ctx->d_counts);
     HIP_TRY(hipGetLastError());
+    return UNET_OK;
+}
+
+int unet_counters(unet_ctx* c, uint64_t* out, int reset) {
+    if (!c || !out) return fail(UNET_E_INVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    // the counting kernels run behind the results on the streams that produced them
+    HIP_TRY(hipStreamSynchronize(c->s_comp));
+    for (auto& sl : c->slot) HIP_TRY(hipStreamSynchronize(sl.s));
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "counter width");
+    HIP_TRY(hipMemcpy(out, c->d_counts, UNET_V_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(c->d_counts, 0, UNET_V_COUNT * sizeof(uint64_t)));
+    return UNET_OK;
+}
+
+int unet_counters_sum(unet_ctx* const* ctxs, uint32_t n_ctx, uint64_t* out, int reset) {
+    if ((n_ctx && !ctxs) || !out) return fail(UNET_E_INVAL, "null argument");
+    for (u32 v = 0; v < UNET_V_COUNT; v++) out[v] = 0;
+    for (u32 i = 0; i < n_ctx; i++) {
+        uint64_t one[UNET_V_COUNT];
+        int rc = unet_counters(ctxs[i], one, reset);
+        if (rc) return rc;
+        for (u32 v = 0; v < UNET_V_COUNT; v++) out[v] += one[v];
+    }
     return UNET_OK;
 }
 
