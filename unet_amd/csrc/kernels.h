@@ -28,7 +28,7 @@ struct Batch {
 #define UNET_MID_PATH 1       // tile_sums: lane groups for records of 81..1024 bytes
 #endif
 #ifndef UNET_OCC64
-#define UNET_OCC64 5          // workgroups per CU of the 64-record-tile kernels (their LDS allows 5)
+#define UNET_OCC64 8          // workgroups per CU the 64-record-tile kernels leave register room for
 #endif
 #ifndef UNET_SPAN_PATH
 #define UNET_SPAN_PATH 1      // tile_sums: tiles of short records staged in LDS as one coalesced byte range
@@ -90,6 +90,20 @@ constexpr u32 kLdsChunksPerRec = UNET_LDS_PER_REC;
 constexpr u32 kRow4Chunks = UNET_ROW4_CHUNKS;  // longer records up to 16 chunks (256 bytes) are handled by 4 lanes,
 constexpr u32 kRow8Chunks = 32;   // up to 32 chunks (512 bytes) by 8 lanes,
 constexpr u32 kMidChunks = 64;    // up to 64 chunks (1024 bytes) by a 16-lane row
+
+// LDS geometry of a tile.  A wave works through its tile in passes of at most 32 records, so that the park area
+// -- and with it the number of workgroups a CU can hold -- does not grow with 64-record tiles: 4.5 KiB per wave
+// lets eight workgroups share a CU (with 7.5 KiB it was five, and short records, which keep few bytes in flight
+// per wave, ran 10 % slower).
+template <int TILE>
+struct TileGeom {
+    static constexpr u32 kPass = TILE < 32 ? (u32)TILE : 32u;   // records per pass; record j is parked at slot j % kPass
+    static constexpr u32 kPasses = (u32)TILE / kPass;           // 1 or 2
+    // chunks of the park area: kPass record areas, rounded up to whole 1 KiB rows for the span route
+    static constexpr u32 kPark = TILE >= 32 ? 256u : kPass * kLdsChunksPerRec;
+    static constexpr u32 kWaveLds = kPark + (2u * (u32)TILE + 3u) / 4u;  // + TILE u32 sums + TILE u32 list entries
+    static_assert(kPark >= kPass * kLdsChunksPerRec, "park area holds a pass of records");
+};
 
 // Header dwords of a lane's own record, parked in LDS.
 struct LdsFetch {
@@ -180,13 +194,13 @@ __device__ __forceinline__ u32x4 pick_chunk(bool first, u32x4 a, u32x4 b) {
 }
 
 // Sum of the full chunks of one streamed record (wave-uniform result); parks header and tail chunk.
-template <bool PARK_HDR>
+template <bool PARK_HDR, u32 PASS>
 __device__ __forceinline__ u32 stream_one(const Rows2& cur, u32 lane, u32x4* __restrict__ park) {
     const u32 nfull = cur.flen >> 4;              // chunks that are summed whole
     const bool partial = (cur.flen & 15u) != 0u;  // chunk `nfull` exists and is cut short
     const bool two = cur.two();
     const u32 i1 = lane + cur.tail_base();        // chunk held by this lane's `tail`
-    u32x4* mine = park + cur.j * kLdsChunksPerRec;
+    u32x4* mine = park + (cur.j % PASS) * kLdsChunksPerRec;
     if (PARK_HDR && lane < kHdrChunks) mine[lane] = pick_chunk(two, cur.head, cur.tail);
     // the cut chunk is the record's last one: always in `tail`
     if (partial && i1 == nfull) mine[kHdrChunks] = cur.tail;
@@ -309,11 +323,11 @@ __device__ __forceinline__ u32 group_sum(u32 v) {
     return v;
 }
 
-template <u32 W, bool PARK_HDR>
+template <u32 W, bool PARK_HDR, u32 PASS>
 __device__ __forceinline__ void consume_rows_step(const RowStep& g, u32 lane, u32x4* __restrict__ park, u32* __restrict__ sums) {
     const u32 sub = lane & (W - 1u);
     const u32 nfull = g.row_live ? g.len >> 4 : 0u;
-    u32x4* mine = park + g.rec * kLdsChunksPerRec;
+    u32x4* mine = park + (g.rec % PASS) * kLdsChunksPerRec;
     if (PARK_HDR && g.row_live) {  // chunks 0..5: in v0 for W >= 8, in v0 and v1 for W = 4
         if (sub < kHdrChunks) mine[sub] = g.v0;
         if (W < kHdrChunks && sub + W < kHdrChunks) mine[sub + W] = g.v1;
@@ -330,7 +344,7 @@ __device__ __forceinline__ void consume_rows_step(const RowStep& g, u32 lane, u3
     if (g.row_live && sub == 0u) sums[g.rec] = acc;
 }
 
-template <u32 W, bool PARK_HDR>
+template <u32 W, bool PARK_HDR, u32 PASS>
 __device__ __forceinline__ void rows_path(const Batch& b, const Tile& t, bool mine_here, u32* __restrict__ list,
                                           u32x4* __restrict__ park, u32* __restrict__ sums) {
     constexpr u32 kPerStep = kWave / W;
@@ -347,71 +361,82 @@ __device__ __forceinline__ void rows_path(const Batch& b, const Tile& t, bool mi
 #pragma nounroll
     while (true) {
         g1 = issue_rows_step<W>(b, t, list, next, count);
-        consume_rows_step<W, PARK_HDR>(g0, t.lane, park, sums);
+        consume_rows_step<W, PARK_HDR, PASS>(g0, t.lane, park, sums);
         if (next >= count) break;
         next += kPerStep;
         g0 = issue_rows_step<W>(b, t, list, next, count);
-        consume_rows_step<W, PARK_HDR>(g1, t.lane, park, sums);
+        consume_rows_step<W, PARK_HDR, PASS>(g1, t.lane, park, sums);
         if (next >= count) break;
         next += kPerStep;
     }
 }
 
-// N fully coalesced streaming 1 KiB loads of the chunks [0, span) at p (indices past the end re-read the last
-// chunk), all issued before the first is parked in LDS.
-template <u32 N>
-__device__ __forceinline__ void stage_span(const u32x4* __restrict__ p, u32 lane, u32 span, u32x4* __restrict__ park) {
-    u32x4 v[N];
-#pragma unroll
-    for (u32 k = 0; k < N; ++k) v[k] = ld_stream(p + min(k * kWave + lane, span - 1u));
-#pragma unroll
-    for (u32 k = 0; k < N; ++k) park[k * kWave + lane] = v[k];
-}
+// ---- span route.  A tile made only of short records (at most 8 chunks each) that lie close together -- any
+// packed or fixed-stride batch of short frames: the byte range that holds the tile's records (at most 256 chunks)
+// is staged in the wave's LDS area with whole 1 KiB streaming rows, all issued up front, and every lane then
+// sums its own record out of LDS.  One lane loading its own 64-byte record straight from memory makes every load
+// instruction touch 32 different 128-byte lines; here each line is requested once.
+constexpr u32 kSpanMaxChunks = 8;
 
-// A tile made only of short records (at most 7 chunks each) that lie close together -- any packed or
-// fixed-stride batch of short frames: the byte range that holds them is staged in the wave's LDS area with whole
-// 1 KiB rows, and every lane then sums its own record out of LDS.  One lane loading its own 64-byte record
-// straight from memory makes every load instruction touch 32 different 128-byte lines; here each line is
-// requested once.  Returns false (nothing done) when the tile does not qualify.
+struct SpanPlan {
+    bool on;               // the tile takes this route
+    u32 base, span, rows;  // first chunk, chunks, 1 KiB rows
+    u32 max_nch;           // longest record of the tile, in chunks
+    u32x4 r0, r1, r2, r3;  // the rows, loads in flight
+};
+
 template <int TILE>
-__device__ __forceinline__ bool span_path(const Batch& b, Tile& t, u32 my_nch, u32x4* __restrict__ park, u32* total) {
-    constexpr u32 kCap = (u32)TILE * kLdsChunksPerRec;  // chunks in the wave's park area
+__device__ __forceinline__ SpanPlan plan_span(const Batch& b, const Tile& t, u32 my_nch) {
+    typedef TileGeom<TILE> G;
+    static_assert(G::kPark <= 4u * kWave, "four rows hold the park area");
+    SpanPlan sp;
+    sp.on = false;
+    sp.base = sp.span = sp.rows = sp.max_nch = 0;
+    sp.r0 = sp.r1 = sp.r2 = sp.r3 = u32x4{0, 0, 0, 0};
     const bool in = t.lane < t.cnt;
-    const bool fits = !in || (t.my_ok && my_nch <= kLdsChunksPerRec && t.my_slot <= 0xfffffff0u);
-    if (__ballot(fits) != ~0ull) return false;
+    const bool fits = !in || (t.my_ok && my_nch <= kSpanMaxChunks && t.my_slot <= 0xfffffff0u);
+    if (__ballot(fits) != ~0ull) return sp;
     const bool some = in && my_nch != 0u;
     const u32 lo = wave_minmax<false>(some ? t.my_slot : 0xffffffffu);
     const u32 end = wave_minmax<true>(some ? t.my_slot + my_nch : 0u);
-    t.my_hdr = park;
-    *total = 0;
-    if (end <= lo) return true;  // nothing but empty records
-    // start on a 128-byte line when the range still fits then
-    const u32 base = end - (lo & ~7u) <= kCap ? (lo & ~7u) : lo;
-    const u32 span = end - base;
-    if (span > kCap) return false;
-    const u32x4* p = reinterpret_cast<const u32x4*>(b.arena) + (u64)base;
-    switch ((span + kWave - 1u) / kWave) {
-        case 1: stage_span<1>(p, t.lane, span, park); break;
-        case 2: stage_span<2>(p, t.lane, span, park); break;
-        case 3: stage_span<3>(p, t.lane, span, park); break;
-        case 4: stage_span<4>(p, t.lane, span, park); break;
-        case 5: stage_span<5>(p, t.lane, span, park); break;
-        case 6: stage_span<6>(p, t.lane, span, park); break;
-        default: stage_span<7>(p, t.lane, span, park); break;
+    if (end > lo) {
+        // start on a 128-byte line when the range still fits then
+        sp.base = end - (lo & ~7u) <= G::kPark ? (lo & ~7u) : lo;
+        sp.span = end - sp.base;
     }
+    if (sp.span > G::kPark) return sp;
+    sp.on = true;
+    sp.rows = (sp.span + kWave - 1u) / kWave;
+    sp.max_nch = wave_minmax<true>(my_nch);
+    const u32x4* p = reinterpret_cast<const u32x4*>(b.arena) + (u64)sp.base;
+    // wave-uniform branches: exactly the rows that exist are requested
+    if (sp.rows > 0u) sp.r0 = ld_stream(p + min(t.lane, sp.span - 1u));
+    if (sp.rows > 1u) sp.r1 = ld_stream(p + min(kWave + t.lane, sp.span - 1u));
+    if (sp.rows > 2u) sp.r2 = ld_stream(p + min(2u * kWave + t.lane, sp.span - 1u));
+    if (sp.rows > 3u) sp.r3 = ld_stream(p + min(3u * kWave + t.lane, sp.span - 1u));
+    return sp;
+}
+
+// The rows go to LDS, every lane sums its own record; t.my_hdr then points at it in LDS.
+template <int TILE>
+__device__ __forceinline__ u32 span_sums(const SpanPlan& sp, Tile& t, u32x4* __restrict__ park) {
+    if (sp.rows > 0u) park[t.lane] = sp.r0;
+    if (sp.rows > 1u) park[kWave + t.lane] = sp.r1;
+    if (sp.rows > 2u) park[2u * kWave + t.lane] = sp.r2;
+    if (sp.rows > 3u) park[3u * kWave + t.lane] = sp.r3;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const u32 rel = some ? t.my_slot - base : 0u;
-    const u32x4* mine = park + rel;
+    const u32 my_nch = (t.my_len + 15u) >> 4;
+    const bool some = t.lane < t.cnt && my_nch != 0u;
+    const u32x4* mine = park + (some ? t.my_slot - sp.base : 0u);
     t.my_hdr = mine;
-    const u32 max_nch = wave_minmax<true>(my_nch);
     const LaneTail tail(t.my_len);
     const bool partial = (t.my_len & 15u) != 0u;
     const u32 nfull = t.my_len >> 4;
     u32 acc = 0;
 #pragma unroll
-    for (u32 k = 0; k < kLdsChunksPerRec; ++k) {
-        if (k < max_nch) {  // wave-uniform
+    for (u32 k = 0; k < kSpanMaxChunks; ++k) {
+        if (k < sp.max_nch) {  // wave-uniform
             u32x4 c = mine[k];
             const u32x4 cut = tail.apply(c);
             const bool whole = k < nfull, last = partial && k == nfull;
@@ -422,37 +447,38 @@ __device__ __forceinline__ bool span_path(const Batch& b, Tile& t, u32 my_nch, u
             acc = sum_chunk(c, acc);
         }
     }
-    *total = some ? acc : 0u;
-    return true;
+    return some ? acc : 0u;
 }
 
-// Exact sum of the lane's own record (0 for lanes without a valid record).  On return t.my_hdr points at the
-// lane's own record in LDS: at least its chunks 0..5 (if PARK_HDR; stale or foreign bytes past the record's end).
+// General route, one pass: exact sum of the lane's own record if it belongs to this pass (lanes pass*kPass ..
+// pass*kPass + kPass - 1), 0 otherwise.  On return t.my_hdr points at the lane's own parked chunks 0..5 (if
+// PARK_HDR; stale bytes past the record's end).
 template <int TILE, bool PARK_HDR>
-__device__ __forceinline__ u32 tile_sums(const Batch& b, Tile& t, u32x4* __restrict__ park) {
-    u32x4* mine = park + t.lane * kLdsChunksPerRec;  // only meaningful for lane < TILE
-    const u32 my_nch = t.my_ok ? (t.my_len + 15u) >> 4 : 0u;
-    if (UNET_SPAN_PATH) {
-        u32 span_total;
-        if (span_path<TILE>(b, t, my_nch, park, &span_total)) return span_total;
-    }
+__device__ __forceinline__ u32 tile_sums(const Batch& b, Tile& t, u32 pass, u32x4* __restrict__ park, bool* mine_now) {
+    typedef TileGeom<TILE> G;
+    constexpr u32 PASS = G::kPass;
+    u32x4* mine = park + (t.lane % PASS) * kLdsChunksPerRec;
+    const bool now = t.lane < t.cnt && (G::kPasses == 1u || t.lane / PASS == pass);
+    *mine_now = now;
+    const bool ok = t.my_ok && now;
+    const u32 my_nch = ok ? (t.my_len + 15u) >> 4 : 0u;
     t.my_hdr = mine;
-    const bool my_small = t.my_ok && my_nch >= 1u && my_nch <= kSmallChunks;
-    const bool my_mid = UNET_MID_PATH && t.my_ok && my_nch > kSmallChunks && my_nch <= kMidChunks;
+    const bool my_small = ok && my_nch >= 1u && my_nch <= kSmallChunks;
+    const bool my_mid = UNET_MID_PATH && ok && my_nch > kSmallChunks && my_nch <= kMidChunks;
     const bool my_row4 = my_mid && my_nch <= kRow4Chunks;
     const bool my_row8 = my_mid && !my_row4 && my_nch <= kRow8Chunks;
-    const bool my_big = t.my_ok && my_nch > kSmallChunks && !my_mid;
+    const bool my_big = ok && my_nch > kSmallChunks && !my_mid;
     const LaneTail tail(t.my_len);
     const bool my_partial = (t.my_len & 15u) != 0u;
     u32 my_total = 0;
 
     // ---- mid-size records (up to 1 KiB), four at a time (its register buffers are free again afterwards)
-    u32* sums = reinterpret_cast<u32*>(park + TILE * kLdsChunksPerRec);  // one u32 per record of the tile
+    u32* sums = reinterpret_cast<u32*>(park + G::kPark);  // one u32 per record of the tile
     u32* list = sums + TILE;                                              // and one list entry
     if (UNET_MID_PATH) {
-        if (kRow4Chunks > kSmallChunks) rows_path<4, PARK_HDR>(b, t, my_row4, list, park, sums);
-        rows_path<8, PARK_HDR>(b, t, my_row8, list, park, sums);
-        rows_path<16, PARK_HDR>(b, t, my_mid && !my_row4 && !my_row8, list, park, sums);
+        if (kRow4Chunks > kSmallChunks) rows_path<4, PARK_HDR, PASS>(b, t, my_row4, list, park, sums);
+        rows_path<8, PARK_HDR, PASS>(b, t, my_row8, list, park, sums);
+        rows_path<16, PARK_HDR, PASS>(b, t, my_mid && !my_row4 && !my_row8, list, park, sums);
     }
 
     // ---- streamed records: their first loads go out before the lane-parallel part
@@ -528,7 +554,7 @@ __device__ __forceinline__ u32 tile_sums(const Batch& b, Tile& t, u32x4* __restr
     // nothing forces an early wait) and the loads of the next record(s) are in flight while one is summed
 #define UNET_CONSUME(R)                                                              \
     {                                                                                \
-        const u32 s_ = stream_one<PARK_HDR>(R, t.lane, park);                        \
+        const u32 s_ = stream_one<PARK_HDR, PASS>(R, t.lane, park);                        \
         if (t.lane == R.j) my_total = s_;                                            \
     }
     if (any_big) {
@@ -568,11 +594,93 @@ __device__ __forceinline__ u32 tile_sums(const Batch& b, Tile& t, u32x4* __restr
     return my_total;
 }
 
-// Per wave: TILE record areas of kLdsChunksPerRec chunks, then TILE u32 sums and TILE u32 list entries.
+// Per wave: the park area, then TILE u32 sums and TILE u32 list entries.
 #define UNET_TILE_LDS(TILE)                                                                         \
-    constexpr u32 kWaveLds = (TILE) * kLdsChunksPerRec + (2u * (TILE) + 3u) / 4u;                   \
+    constexpr u32 kWaveLds = TileGeom<TILE>::kWaveLds;                                              \
     __shared__ u32x4 lds[(kBlock / kWave) * kWaveLds];                                              \
     u32x4* park = lds + (threadIdx.x >> 6) * kWaveLds
+
+// General route of the 64-record tiles, which exist for batches of short records (the host picks them only when
+// it has reason to expect such a batch): a tile that cannot take the span route -- a long record in it, records
+// scattered over the arena -- is read by plain per-lane loops, 32 records per pass, four loads in flight per
+// lane.  Any length is handled; it is simply not fast for long records, and it is cheap in registers, which is
+// what lets these kernels keep eight workgroups on a CU for the route they are meant for.
+template <int TILE, bool PARK_HDR>
+__device__ __forceinline__ u32 lane_loop_pass(const Batch& b, Tile& t, u32 pass, u32x4* __restrict__ park, bool* mine_now) {
+    constexpr u32 PASS = TileGeom<TILE>::kPass;
+    u32x4* mine = park + (t.lane % PASS) * kLdsChunksPerRec;
+    const bool now = t.lane < t.cnt && (TileGeom<TILE>::kPasses == 1u || t.lane / PASS == pass);
+    *mine_now = now;
+    t.my_hdr = mine;
+    const bool ok = t.my_ok && now;
+    const u32 nch = ok ? (t.my_len + 15u) >> 4 : 0u;
+    const u32 nfull = t.my_len >> 4;
+    const bool partial = (t.my_len & 15u) != 0u;
+    const LaneTail tail(t.my_len);
+    const u32x4* p = reinterpret_cast<const u32x4*>(b.arena + (ok ? (u64)t.my_slot * 16u : 0ull));
+    const u32 last = nch != 0u ? nch - 1u : 0u;
+    u32 acc = 0;
+#pragma nounroll
+    for (u32 c = 0; c < nch; c += 4u) {
+        const u32x4 v0 = ld_small(p + min(c, last)), v1 = ld_small(p + min(c + 1u, last));
+        const u32x4 v2 = ld_small(p + min(c + 2u, last)), v3 = ld_small(p + min(c + 3u, last));
+        if (PARK_HDR && c == 0u) {
+            mine[0] = v0;
+            mine[1] = v1;
+            mine[2] = v2;
+            mine[3] = v3;
+        }
+        if (PARK_HDR && c == 4u) {
+            mine[4] = v0;
+            mine[5] = v1;
+        }
+#define UNET_LOOP_USE(V, I)                                                         \
+        {                                                                           \
+            const u32 k_ = c + (I);                                                 \
+            const bool whole_ = k_ < nfull, cut_ = partial && k_ == nfull;          \
+            const u32x4 m_ = tail.apply(V);                                         \
+            u32x4 u_;                                                               \
+            u_.x = whole_ ? V.x : (cut_ ? m_.x : 0u);                               \
+            u_.y = whole_ ? V.y : (cut_ ? m_.y : 0u);                               \
+            u_.z = whole_ ? V.z : (cut_ ? m_.z : 0u);                               \
+            u_.w = whole_ ? V.w : (cut_ ? m_.w : 0u);                               \
+            acc = sum_chunk(u_, acc);                                               \
+        }
+        UNET_LOOP_USE(v0, 0u) UNET_LOOP_USE(v1, 1u) UNET_LOOP_USE(v2, 2u) UNET_LOOP_USE(v3, 3u)
+#undef UNET_LOOP_USE
+    }
+    // LDS written here is read back by the caller
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return acc;
+}
+
+// Works through a tile: fin(total, mine_now) is called once per pass by the whole wave, with `mine_now` set for
+// the lanes whose record was handled in that pass, `total` = that record's exact byte sum and t.my_hdr = its first
+// chunks in LDS.  The LDS area is reused by the next pass.  The two routes are kept apart (rather than chosen
+// inside one loop) so that the staged rows of the span route never share registers' lifetimes with the rotation
+// buffers of the general route.
+template <int TILE, bool PARK_HDR, class Fin>
+__device__ __forceinline__ void tile_run(const Batch& b, Tile& t, u32x4* __restrict__ park, Fin&& fin) {
+    if (UNET_SPAN_PATH) {
+        const SpanPlan sp = plan_span<TILE>(b, t, t.my_ok ? (t.my_len + 15u) >> 4 : 0u);
+        if (sp.on) {
+            const u32 total = span_sums<TILE>(sp, t, park);
+            fin(total, t.lane < t.cnt);
+            return;
+        }
+    }
+#pragma nounroll
+    for (u32 pass = 0; pass < TileGeom<TILE>::kPasses; ++pass) {
+        bool mine_now;
+        u32 total;
+        if constexpr (TileGeom<TILE>::kPasses > 1u) total = lane_loop_pass<TILE, PARK_HDR>(b, t, pass, park, &mine_now);
+        else total = tile_sums<TILE, PARK_HDR>(b, t, pass, park, &mine_now);
+        fin(total, mine_now);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 
 // ---------------------------------------------------------------- a1: calculate_checksum
 // out[i] = calculate_checksum(record i, seeds[i])  (src/utils.rs:1-17)
@@ -585,9 +693,11 @@ __global__ __launch_bounds__(kBlock, TILE == 64 ? UNET_OCC64 : 6) void k_csum(Ba
     if (!t.init<TILE>(b)) return;
     u32 my_seed = 0;
     if (seeds && t.lane < t.cnt) my_seed = seeds[t.first + t.lane];
-    const u32 total = tile_sums<TILE, false>(b, t, park);
-    // the seed is an already-folded partial sum in the big-endian domain (src/utils.rs:2)
-    const u32 res = t.my_ok ? finish(total + bswap16(my_seed)) : 0u;
+    u32 res = 0;
+    tile_run<TILE, false>(b, t, park, [&](u32 total, bool mine_now) {
+        // the seed is an already-folded partial sum in the big-endian domain (src/utils.rs:2)
+        if (mine_now && t.my_ok) res = finish(total + bswap16(my_seed));
+    });
     if (t.lane < t.cnt) out[t.first + t.lane] = (uint16_t)res;
 }
 
@@ -598,14 +708,15 @@ __global__ __launch_bounds__(kBlock, TILE == 64 ? UNET_OCC64 : 6) void k_verify(
     UNET_TILE_LDS(TILE);
     Tile t;
     if (!t.init<TILE>(b)) return;
-    const u32 total = tile_sums<TILE, true>(b, t, park);
     u32 res = 0;  // V_NONE for records whose length/offset is out of range
-    if (t.my_ok) {
-        LdsFetch f;
-        f.w = reinterpret_cast<const u32*>(t.my_hdr);
-        const Parsed P = parse_record<MODE>(f, t.my_len, ifc);
-        res = P.kind == K_DONE ? P.res : finalize_record(P, total);
-    }
+    tile_run<TILE, true>(b, t, park, [&](u32 total, bool mine_now) {
+        if (mine_now && t.my_ok) {
+            LdsFetch f;
+            f.w = reinterpret_cast<const u32*>(t.my_hdr);
+            const Parsed P = parse_record<MODE>(f, t.my_len, ifc);
+            res = P.kind == K_DONE ? P.res : finalize_record(P, total);
+        }
+    });
     if (t.lane < t.cnt) out[t.first + t.lane] = res;
 }
 
@@ -687,10 +798,10 @@ __global__ __launch_bounds__(kBlock, TILE == 64 ? UNET_OCC64 : 6) void k_generat
     UNET_TILE_LDS(TILE);
     Tile t;
     if (!t.init<TILE>(b)) return;
-    const u32 total = tile_sums<TILE, true>(b, t, park);
     u32 st = V_DROP_L3_TRUNCATED;  // also reported for out-of-range lengths/offsets
     u32 my_fields = 0;
-    if (t.my_ok && t.my_len >= 20u) {
+    tile_run<TILE, true>(b, t, park, [&](u32 total, bool mine_now) {
+    if (mine_now && t.my_ok && t.my_len >= 20u) {
         const u32* w = reinterpret_cast<const u32*>(t.my_hdr);
         const u32 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
         const u32 proto = (w2 >> 8) & 0xffu;
@@ -731,6 +842,7 @@ __global__ __launch_bounds__(kBlock, TILE == 64 ? UNET_OCC64 : 6) void k_generat
             }
         }
     }
+    });
     if (!IN_PLACE && t.lane < t.cnt) fields[t.first + t.lane] = my_fields;
     if (status && t.lane < t.cnt) status[t.first + t.lane] = (uint8_t)st;
 }

@@ -179,6 +179,8 @@ struct unet_ctx {
     int tx_tile_override = 0;     // UNET_TX_TILE (4, 8, 16, 32, 64), read once at unet_open
     bool hdr_plain = false;       // UNET_HDR_PLAIN, read once at unet_open
     u32 mean_len_hint = 0;        // unet_hint_mean_len
+    bool len_known = false;       // set by the host-pointer entry points around their *_dev call
+    u32 mean_len_known = 0, max_len_known = 0;
     uint8_t* scratch_dev = nullptr;  // this device's copy of the static scratch array
     unsigned long long* d_counts = nullptr;  // UNET_V_COUNT per-verdict counters of the host-pointer entry points
     hipEvent_t results_ready = nullptr;
@@ -262,16 +264,26 @@ int check_batch(unet_ctx* ctx, const void* arena, const void* off16, u32 stride1
 inline bool arena_too_small(u64 arena_bytes) { return arena_bytes < 16; }
 // Records per wave: long records want short tiles (fine-grained tail of the launch), short records
 // want many lanes busy in the lane-parallel phase.
-inline int tile_for_mean(u64 mean_len) { return mean_len >= 1024 ? 16 : (mean_len >= 256 ? 32 : 64); }
+// Records per wave.  16 for long records (fine-grained tail of the launch), 32 below 1 KiB, and 64-record tiles
+// for batches of the shortest records only (at most 64 bytes): their kernel stages a tile's byte range in LDS when
+// it fits 4 KiB and reads any other tile with plain per-lane loops (correct for every length, slow for long
+// ones).  So it is chosen when the longest record is known to be that short, or -- lengths unseen -- when the
+// mean is so low that hardly any record can be longer.
+constexpr u64 kShortMax = 64;
+inline int tile_for(u64 mean_len, bool max_known, u64 max_len) {
+    if (mean_len >= 1024) return 16;
+    const bool all_short = max_known ? max_len <= kShortMax : mean_len <= kShortMax;
+    return all_short ? 64 : 32;
+}
 // The device-pointer entry points cannot see the lengths: the mean record size is the caller's hint if one was
-// given (unet_hint_mean_len), else the fixed stride, else arena_bytes / n (right for packed arenas).  The
-// host-pointer entry points pass the true mean.
-inline int pick_tile(const unet_ctx* c, u64 arena_bytes, u32 stride16, u32 n, u64 true_mean = ~0ull) {
+// given (unet_hint_mean_len), else the fixed stride (which also bounds the length), else arena_bytes / n (right
+// for packed arenas).  The host-pointer entry points pass the true mean and maximum.
+inline int pick_tile(const unet_ctx* c, u64 arena_bytes, u32 stride16, u32 n) {
     if (c->tile_override) return c->tile_override;
-    if (true_mean != ~0ull) return tile_for_mean(true_mean);
-    if (c->mean_len_hint) return tile_for_mean(c->mean_len_hint);
-    if (stride16) return tile_for_mean((u64)stride16 * 16u);
-    return tile_for_mean(arena_bytes / n);
+    if (c->len_known) return tile_for(c->mean_len_known, true, c->max_len_known);
+    if (c->mean_len_hint) return tile_for(c->mean_len_hint, false, 0);
+    if (stride16) return tile_for((u64)stride16 * 16u, true, (u64)stride16 * 16u);
+    return tile_for(arena_bytes / n, false, 0);
 }
 
 inline hipStream_t pick(unet_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->s_comp; }
@@ -282,9 +294,10 @@ inline u32 tiles_grid(u32 n, u32 tile) {
 
 // Shared body of the host-pointer batch calls: upload arena + tables, leave device views in `b`.
 int upload_batch(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16, uint32_t stride16,
-                 const uint32_t* len, uint32_t n, Batch* b, u32* mean_len) {
+                 const uint32_t* len, uint32_t n, Batch* b, u32* mean_len, u32* max_len) {
     // every record (plus its pad to 16 bytes) must lie inside the caller's arena
     u64 sum_len = 0;
+    u32 longest = 0;
     for (u32 i = 0; i < n; i++) {
         if (len[i] > kMaxLen) return fail(UNET_E_RANGE, "record %u: length %u > 65535", i, len[i]);
         const u64 slot = off16 ? off16[i] : (u64)i * stride16;
@@ -292,8 +305,10 @@ int upload_batch(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const 
         const u64 end = slot * 16u + (((u64)len[i] + 15u) & ~15ull);
         if (end > arena_bytes) return fail(UNET_E_RANGE, "record %u ends at byte %llu, arena is %llu bytes (records are read in 16-byte chunks)", i, (unsigned long long)end, (unsigned long long)arena_bytes);
         sum_len += len[i];
+        if (len[i] > longest) longest = len[i];
     }
     if (mean_len) *mean_len = (u32)(sum_len / n);
+    if (max_len) *max_len = longest;
     int rc;
     if ((rc = ensure(c, c->d_arena, arena_bytes))) return rc;
     if ((rc = ensure(c, c->d_len, (size_t)n * 4))) return rc;
@@ -330,23 +345,28 @@ int launch_verify(hipStream_t s, const Batch& b, const unet_iface* iface, int ti
     return UNET_OK;
 }
 
-// The host-pointer entry points know the true mean record length; it steers the tile choice of the *_dev call
-// they make.
-struct MeanScope {
+// The host-pointer entry points have seen the lengths; that steers the tile choice of the *_dev call they make.
+struct LenScope {
     unet_ctx* c;
-    u32 old;
-    MeanScope(unet_ctx* ctx, u32 mean) : c(ctx), old(ctx->mean_len_hint) { c->mean_len_hint = mean ? mean : 1u; }
-    ~MeanScope() { c->mean_len_hint = old; }
+    LenScope(unet_ctx* ctx, u32 mean, u32 max) : c(ctx) {
+        c->len_known = true;
+        c->mean_len_known = mean;
+        c->max_len_known = max;
+    }
+    ~LenScope() { c->len_known = false; }
 };
 
 // One batch as a single staging image [len | off16 | arena bytes that hold records]: one host-to-device copy.
 struct Image {
     u64 at_off, at_arena, used, total, sum_len;
+    u32 max_len;
 };
 
 int plan_image(uint64_t arena_bytes, const uint32_t* off16, uint32_t stride16, const uint32_t* len, uint32_t n, Image* im) {
     u64 used = 16, sum_len = 0;
+    u32 longest = 0;
     for (u32 i = 0; i < n; i++) {
+        if (len[i] > longest) longest = len[i];
         if (len[i] > kMaxLen) return fail(UNET_E_RANGE, "record %u: length %u > 65535", i, len[i]);
         const u64 slot = off16 ? off16[i] : (u64)i * stride16;
         if (slot > 0xffffffffull) return fail(UNET_E_RANGE, "record %u starts past 2^32 16-byte slots", i);
@@ -361,6 +381,7 @@ int plan_image(uint64_t arena_bytes, const uint32_t* off16, uint32_t stride16, c
     im->used = used;
     im->total = im->at_arena + used;
     im->sum_len = sum_len;
+    im->max_len = longest;
     return UNET_OK;
 }
 
@@ -534,9 +555,9 @@ int unet_csum_batch(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, con
     if (!off16 && stride16 == 0) return fail(UNET_E_INVAL, "need an offset table or a non-zero stride");
     HIP_TRY(hipSetDevice(c->device));
     Batch b;
-    u32 mean = 0;
-    int rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b, &mean);
-    MeanScope hint(c, mean);
+    u32 mean = 0, maxlen = 0;
+    int rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b, &mean, &maxlen);
+    LenScope hint(c, mean, maxlen);
     if (rc) return rc;
     if ((rc = ensure(c, c->d_out, (size_t)n * 2))) return rc;
     const uint16_t* d_seeds = nullptr;
@@ -659,7 +680,7 @@ int unet_verify(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const u
         uint8_t* dev = (uint8_t*)c->d_arena.p;
         HIP_TRY(hipMemcpyAsync(dev, c->pinned[0], im.total, hipMemcpyHostToDevice, c->s_comp));
         u32* d_out = (u32*)(dev + res_at);
-        const int tile = c->tile_override ? c->tile_override : tile_for_mean(im.sum_len / n);
+        const int tile = c->tile_override ? c->tile_override : tile_for(im.sum_len / n, true, im.max_len);
         if ((rc = launch_verify(c->s_comp, image_batch(dev, im, off16 != nullptr, stride16, n), iface, tile, d_out))) return rc;
         HIP_TRY(hipMemcpyAsync(c->pinned[1], d_out, (size_t)n * 4u, hipMemcpyDeviceToHost, c->s_comp));
         HIP_TRY(hipEventRecord(c->results_ready, c->s_comp));
@@ -669,9 +690,9 @@ int unet_verify(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const u
         return UNET_OK;
     }
     Batch b;
-    u32 mean = 0;
-    rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b, &mean);
-    MeanScope hint(c, mean);
+    u32 mean = 0, maxlen = 0;
+    rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b, &mean, &maxlen);
+    LenScope hint(c, mean, maxlen);
     if (rc) return rc;
     if ((rc = ensure(c, c->d_out, (size_t)n * 4))) return rc;
     rc = unet_verify_dev(c, nullptr, b.arena, b.arena_bytes, b.off16, b.stride16, b.len, n, iface, (unet_result*)c->d_out.p);
@@ -713,7 +734,7 @@ int unet_verify_async(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, c
     uint8_t* dev = (uint8_t*)sl.dev.p;
     HIP_TRY(hipMemcpyAsync(dev, sl.pin, im.total, hipMemcpyHostToDevice, sl.s));
     u32* d_out = (u32*)(dev + res_at);
-    const int tile = c->tile_override ? c->tile_override : tile_for_mean(im.sum_len / n);
+    const int tile = c->tile_override ? c->tile_override : tile_for(im.sum_len / n, true, im.max_len);
     if ((rc = launch_verify(sl.s, image_batch(dev, im, off16 != nullptr, stride16, n), iface, tile, d_out))) return rc;
     HIP_TRY(hipMemcpyAsync((uint8_t*)sl.pin + res_at, d_out, (size_t)n * 4u, hipMemcpyDeviceToHost, sl.s));
     HIP_TRY(hipEventRecord(sl.done, sl.s));
@@ -768,7 +789,7 @@ int unet_verify_static(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, 
     uint8_t* dev = c->scratch_dev;  // never the array's name: that is not a device address in host code
     HIP_TRY(hipMemcpyAsync(dev, c->pinned[0], im.total, hipMemcpyHostToDevice, c->s_comp));
     u32* d_out = (u32*)(dev + kStaticOutAt);
-    const int tile = c->tile_override ? c->tile_override : tile_for_mean(im.sum_len / n);
+    const int tile = c->tile_override ? c->tile_override : tile_for(im.sum_len / n, true, im.max_len);
     if ((rc = launch_verify(c->s_comp, image_batch(dev, im, off16 != nullptr, stride16, n), iface, tile, d_out))) return rc;
     HIP_TRY(hipMemcpyAsync(c->pinned[1], d_out, (size_t)n * 4u, hipMemcpyDeviceToHost, c->s_comp));
     HIP_TRY(hipEventRecord(c->results_ready, c->s_comp));
@@ -824,9 +845,9 @@ int unet_generate(unet_ctx* c, uint8_t* arena, uint64_t arena_bytes, const uint3
     if (!off16 && stride16 == 0) return fail(UNET_E_INVAL, "need an offset table or a non-zero stride");
     HIP_TRY(hipSetDevice(c->device));
     Batch b;
-    u32 mean = 0;
-    int rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b, &mean);
-    MeanScope hint(c, mean);
+    u32 mean = 0, maxlen = 0;
+    int rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b, &mean, &maxlen);
+    LenScope hint(c, mean, maxlen);
     if (rc) return rc;
     // the GPU computes the two checksum values per packet; only those 4 bytes (and the status) travel
     // back, and are stored into the caller's packets here
@@ -925,9 +946,9 @@ int unet_tx_build(unet_ctx* c, const uint8_t* payload_arena, uint64_t payload_ar
     if (out_arena_bytes < need) return fail(UNET_E_RANGE, "output arena of %llu bytes, need %llu", (unsigned long long)out_arena_bytes, (unsigned long long)need);
     HIP_TRY(hipSetDevice(c->device));
     Batch b;
-    u32 mean = 0;
-    if ((rc = upload_batch(c, payload_arena, payload_arena_bytes, payload_off16, payload_stride16, payload_len, n, &b, &mean))) return rc;
-    MeanScope hint(c, mean);
+    u32 mean = 0, maxlen = 0;
+    if ((rc = upload_batch(c, payload_arena, payload_arena_bytes, payload_off16, payload_stride16, payload_len, n, &b, &mean, &maxlen))) return rc;
+    LenScope hint(c, mean, maxlen);
     // tables: descriptors | output offsets | output lengths | status
     const size_t o_desc = 0, o_off = (size_t)n * sizeof(unet_tx_desc), o_len = o_off + (size_t)n * 4, o_st = o_len + (size_t)n * 4;
     if ((rc = ensure(c, c->d_tx_tab, o_st + n))) return rc;
