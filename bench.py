@@ -230,6 +230,8 @@ class Batch:
             self.rx = unet_amd.Iface("198.51.100.7", "255.255.255.0", mac=bytes.fromhex("02c0ffee0007"), mode=1 if l2 else 0)
             self.tx_ifc = ifc.replace(mode=1 if l2 else 0)
             self.ostride = 95 if l2 else 94  # 1514 / 1500 bytes in 16-byte slots
+            if os.environ.get("UNET_BENCH_TX_OSTRIDE"):  # experiment: packets on 128-byte lines (96)
+                self.ostride = int(os.environ["UNET_BENCH_TX_OSTRIDE"])
             desc = np.zeros(self.n, dtype=TX_DESC_DTYPE)
             desc["dst_mac"] = np.frombuffer(bytes(self.rx.mac), dtype=np.uint8)
             rng = np.random.default_rng(SEED + first_idx)

@@ -135,14 +135,16 @@ __global__ __launch_bounds__(256) void k_copy_piece_pipe(const u32x4* __restrict
 // One table-described record per wave, the way a packet builder meets its input: wave w reads off[w], len[w]
 // and out_off[w] (wave-uniform, so scalar loads), copies the record's chunks with two clamped 1 KiB row loads
 // and stores them 28 bytes further (header room), i.e. through a one-lane shift like the real kernel.
+template <bool TABLES>
 __global__ __launch_bounds__(256) void k_copy_record_wave(const u32x4* __restrict__ src, u32x4* __restrict__ dst, const u32* __restrict__ off,
-                                                          const u32* __restrict__ len, const u32* __restrict__ out_off, u32 n) {
+                                                          const u32* __restrict__ len, const u32* __restrict__ out_off, u32 n,
+                                                          u32 in_stride, u32 out_stride) {
     const u32 lane = threadIdx.x & 63u;
     const u32 w = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (w >= n) return;
-    const u32 l = len[w], nch = (l + 15u) >> 4, last = nch - 1u;
-    const u32x4* p = src + off[w];
-    u32x4* q = dst + out_off[w];
+    const u32 l = TABLES ? len[w] : 1500u, nch = (l + 15u) >> 4, last = nch - 1u;
+    const u32x4* p = src + (TABLES ? off[w] : w * in_stride);
+    u32x4* q = dst + (TABLES ? out_off[w] : w * out_stride);
     const u32x4 a = __builtin_nontemporal_load(p + min(lane, last));
     const u32x4 b = __builtin_nontemporal_load(p + min(lane + 64u, last));
     if (lane < nch) __builtin_nontemporal_store(a, q + lane);
@@ -229,19 +231,22 @@ int main(int argc, char** argv) {
     PIPE(2, 2, 2, 4) PIPE(2, 2, 2, 16) PIPE(4, 2, 2, 2) PIPE(4, 2, 2, 4) PIPE(4, 2, 2, 8) PIPE(4, 2, 2, 16) PIPE(8, 2, 2, 4) PIPE(8, 2, 2, 16)
     PIPE(4, 2, 0, 4) PIPE(4, 0, 0, 4)
     {
-        // 1504-byte records (94 chunks) packed back to back, described by tables
-        const u32 nrec = (u32)(n / 94);
-        u32 *h = (u32*)malloc(3ull * nrec * 4), *dt;
-        for (u32 i = 0; i < nrec; i++) { h[i] = i * 94u; h[nrec + i] = 1500u; h[2 * nrec + i] = i * 94u; }
-        CK(hipMalloc(&dt, 3ull * nrec * 4));
-        CK(hipMemcpy(dt, h, 3ull * nrec * 4, hipMemcpyHostToDevice));
-        for (int block : {64, 128, 256}) {
-            const int grid = (int)((nrec + block / 64 - 1) / (block / 64));
-            double ms = timeit([&] { hipLaunchKernelGGL(k_copy_record_wave, dim3(grid), dim3(block), 0, 0, (const u32x4*)s, (u32x4*)d, dt, dt + nrec, dt + 2 * nrec, nrec); }, 6);
-            printf("%-34s grid %6d block %4d : %7.3f ms  %7.1f GB/s\n", "one 1500-B record per wave, tables", grid, block, ms, 2.0 * nrec * 1504.0 / ms / 1e6);
+        // 1500-byte records described by tables or by a fixed stride; stride 94 chunks = packed (rows start on any
+        // 16-byte boundary), 96 = every record starts on a 128-byte line
+        for (u32 is : {94u, 96u}) for (u32 os : {94u, 96u}) {
+            const u32 nrec = (u32)(n / 96);
+            u32 *h = (u32*)malloc(3ull * nrec * 4), *dt;
+            for (u32 i = 0; i < nrec; i++) { h[i] = i * is; h[nrec + i] = 1500u; h[2 * nrec + i] = i * os; }
+            CK(hipMalloc(&dt, 3ull * nrec * 4));
+            CK(hipMemcpy(dt, h, 3ull * nrec * 4, hipMemcpyHostToDevice));
+            const int block = 256, grid = (int)((nrec + 3) / 4);
+            double ms = timeit([&] { hipLaunchKernelGGL(k_copy_record_wave<true>, dim3(grid), dim3(block), 0, 0, (const u32x4*)s, (u32x4*)d, dt, dt + nrec, dt + 2 * nrec, nrec, is, os); }, 6);
+            printf("1500-B record per wave, tables, in stride %u out stride %u : %7.3f ms  %7.1f GB/s\n", is, os, ms, 2.0 * nrec * 1504.0 / ms / 1e6);
+            ms = timeit([&] { hipLaunchKernelGGL(k_copy_record_wave<false>, dim3(grid), dim3(block), 0, 0, (const u32x4*)s, (u32x4*)d, dt, dt + nrec, dt + 2 * nrec, nrec, is, os); }, 6);
+            printf("1500-B record per wave, no tables, in stride %u out stride %u : %7.3f ms  %7.1f GB/s\n", is, os, ms, 2.0 * nrec * 1504.0 / ms / 1e6);
+            CK(hipFree(dt));
+            free(h);
         }
-        CK(hipFree(dt));
-        free(h);
     }
     // write only (GB/s here = written bytes * 2 / time, halve it)
     {

@@ -8,7 +8,10 @@
 
 namespace unetdev {
 
-constexpr u32 kBlock = 256;      // 4 waves
+#ifndef UNET_BLOCK
+#define UNET_BLOCK 256
+#endif
+constexpr u32 kBlock = UNET_BLOCK;  // 4 waves
 constexpr u32 UNET_TX_OK_ = 0, UNET_TX_E_PROTO_ = 1, UNET_TX_E_TOO_LONG_ = 2, UNET_TX_E_RANGE_ = 3;  // = UNET_TX_* of the C header
 constexpr u32 kMaxLen = 65535;   // IPv4 maximum (src/protocols/ipv4.rs:18), loopback MTU (src/devices/loopback.rs:16)
 
@@ -58,6 +61,15 @@ __device__ __forceinline__ u32x4 ld_stream(const u32x4* p) { return __builtin_no
 __device__ __forceinline__ u32x4 ld_row(const u32x4* p) { return (UNET_NT_MASK & 1) ? __builtin_nontemporal_load(p) : *p; }
 __device__ __forceinline__ u32x4 ld_small(const u32x4* p) { return (UNET_NT_MASK & 2) ? __builtin_nontemporal_load(p) : *p; }
 __device__ __forceinline__ u32x4 ld_far(const u32x4* p) { return (UNET_NT_MASK & 4) ? __builtin_nontemporal_load(p) : *p; }
+#ifndef UNET_NT_W16
+#define UNET_NT_W16 0
+#endif
+#ifndef UNET_NT_W8
+#define UNET_NT_W8 0
+#endif
+#ifndef UNET_NT_W4
+#define UNET_NT_W4 0
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Tile machinery shared by k_verify, k_csum and k_generate.
@@ -306,10 +318,12 @@ __device__ __forceinline__ RowStep issue_rows_step(const Batch& b, const Tile& t
     const u32 nch = g.row_live ? (g.len + 15u) >> 4 : 0u;
     const u32 last = nch != 0u ? nch - 1u : 0u;
     const u32x4* p = reinterpret_cast<const u32x4*>(b.arena + (g.row_live ? (u64)slot * 16u : 0ull));
-    g.v0 = p[min(sub, last)];
-    g.v1 = p[min(sub + W, last)];
-    g.v2 = p[min(sub + 2u * W, last)];
-    g.v3 = p[min(sub + 3u * W, last)];
+    // bit k of the mask: load k streams past the cache (see the cache-policy note at the top)
+    constexpr u32 nt = W == 16u ? UNET_NT_W16 : (W == 8u ? UNET_NT_W8 : UNET_NT_W4);
+    g.v0 = (nt & 1u) ? ld_stream(p + min(sub, last)) : p[min(sub, last)];
+    g.v1 = (nt & 2u) ? ld_stream(p + min(sub + W, last)) : p[min(sub + W, last)];
+    g.v2 = (nt & 4u) ? ld_stream(p + min(sub + 2u * W, last)) : p[min(sub + 2u * W, last)];
+    g.v3 = (nt & 8u) ? ld_stream(p + min(sub + 3u * W, last)) : p[min(sub + 3u * W, last)];
     return g;
 }
 
@@ -685,7 +699,7 @@ __device__ __forceinline__ void tile_run(const Batch& b, Tile& t, u32x4* __restr
 // ---------------------------------------------------------------- a1: calculate_checksum
 // out[i] = calculate_checksum(record i, seeds[i])  (src/utils.rs:1-17)
 template <int TILE>
-__global__ __launch_bounds__(kBlock, TILE == 64 ? UNET_OCC64 : 6) void k_csum(Batch b, const uint16_t* __restrict__ seeds,
+__global__ __launch_bounds__(kBlock, (TILE == 64 ? UNET_OCC64 : 6) * (256 / UNET_BLOCK)) void k_csum(Batch b, const uint16_t* __restrict__ seeds,
                                                     uint16_t* __restrict__ out) {
     static_assert(TILE >= 1 && TILE <= 64, "one lane per record of the tile");
     UNET_TILE_LDS(TILE);
@@ -703,7 +717,7 @@ __global__ __launch_bounds__(kBlock, TILE == 64 ? UNET_OCC64 : 6) void k_csum(Ba
 
 // ------------------------------------------- a2-a6, a8, a11: receive-path verdicts
 template <int MODE, int TILE>
-__global__ __launch_bounds__(kBlock, TILE == 64 ? UNET_OCC64 : 6) void k_verify(Batch b, IfaceDev ifc, u32* __restrict__ out) {
+__global__ __launch_bounds__(kBlock, (TILE == 64 ? UNET_OCC64 : 6) * (256 / UNET_BLOCK)) void k_verify(Batch b, IfaceDev ifc, u32* __restrict__ out) {
     static_assert(TILE >= 1 && TILE <= 64, "one lane per record of the tile");
     UNET_TILE_LDS(TILE);
     Tile t;
@@ -792,7 +806,7 @@ __global__ __launch_bounds__(kBlock) void k_ipv4_validate_rows(const u32x4* __re
 // IN_PLACE = false leaves the packets alone and writes the two values to fields[i] = ip_csum | l4_csum << 16
 // instead (0 for a record that is not filled): a pure read pass.
 template <int TILE, bool IN_PLACE>
-__global__ __launch_bounds__(kBlock, TILE == 64 ? UNET_OCC64 : 6) void k_generate(Batch b, uint8_t* __restrict__ arena_rw,
+__global__ __launch_bounds__(kBlock, (TILE == 64 ? UNET_OCC64 : 6) * (256 / UNET_BLOCK)) void k_generate(Batch b, uint8_t* __restrict__ arena_rw,
                                                         u32* __restrict__ fields, uint8_t* __restrict__ status) {
     static_assert(TILE >= 1 && TILE <= 64, "one lane per record of the tile");
     UNET_TILE_LDS(TILE);
@@ -1158,11 +1172,14 @@ __device__ __forceinline__ void tx_rows_path(const Batch& pay, const Tile& t, bo
 // Lane j first prepares packet j's headers (every field and the IPv4 checksum; the L4 checksum as a
 // partial sum) and parks them in LDS; the wave then builds the packets one after another, reading each
 // payload once and writing each packet once, in whole 1 KiB rows from its first byte.
+#ifndef UNET_TX_DEPTH
+#define UNET_TX_DEPTH 3
+#endif
 #ifndef UNET_TX_OCC
 #define UNET_TX_OCC 1   // workgroups per CU the register allocator must leave room for
 #endif
 template <int MODE, int TILE>
-__global__ __launch_bounds__(kBlock, UNET_TX_OCC) void k_tx_build(Batch pay, const TxDesc* __restrict__ desc, IfaceDev ifc,
+__global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx_build(Batch pay, const TxDesc* __restrict__ desc, IfaceDev ifc,
                                                      uint8_t* __restrict__ out_arena, u64 out_bytes,
                                                      const u32* __restrict__ out_off16, u32* __restrict__ out_len,
                                                      uint8_t* __restrict__ status) {
@@ -1199,7 +1216,8 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC) void k_tx_build(Batch pay, con
     const bool my_g8 = my_mid && !my_g4 && t.my_len <= 16u * (32u - SH);
 
     u64 todo = __ballot(my_go && !my_small && !my_mid);
-    TxRows A, B, C;
+    constexpr int D = UNET_TX_DEPTH;  // register buffers in rotation: D - 1 payloads' loads in flight while one packet is built
+    TxRows buf[D];
 #define UNET_NEXT(X)                                                                 \
     {                                                                                \
         const bool has = todo != 0ull;                                               \
@@ -1210,8 +1228,8 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC) void k_tx_build(Batch pay, con
     const bool any = todo != 0ull;
     const u64 mid_mask = __ballot(my_mid);
     if (any && mid_mask == 0ull) {  // the first payloads are on their way while the headers are prepared
-        UNET_NEXT(A)
-        UNET_NEXT(B)
+#pragma unroll
+        for (int k = 0; k < D - 1; ++k) UNET_NEXT(buf[k])
     }
 
     // ---- headers as big-endian 16-bit words, checksums in that domain
@@ -1280,8 +1298,8 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC) void k_tx_build(Batch pay, con
         tx_rows_path<8, R, SH>(pay, t, my_g8, frame_len, my_oslot, my_partial, my_udp, list, out_arena, park);
         tx_rows_path<16, R, SH>(pay, t, my_mid && !my_g4 && !my_g8, frame_len, my_oslot, my_partial, my_udp, list, out_arena, park);
         if (any) {
-            UNET_NEXT(A)
-            UNET_NEXT(B)
+#pragma unroll
+            for (int k = 0; k < D - 1; ++k) UNET_NEXT(buf[k])
         }
     }
 
@@ -1297,17 +1315,17 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC) void k_tx_build(Batch pay, con
                         reinterpret_cast<u32x4*>(out_arena + (u64)rdlane(my_oslot, X.j) * 16u), park + X.j * SH, \
                         rdlane(my_partial, X.j), rdlane((u32)my_udp, X.j) != 0u);
     if (any) {
+        bool more = true;
 #pragma nounroll
-        while (true) {
-            UNET_NEXT(C)
-            UNET_CONSUME(A)
-            if (!B.live) break;
-            UNET_NEXT(A)
-            UNET_CONSUME(B)
-            if (!C.live) break;
-            UNET_NEXT(B)
-            UNET_CONSUME(C)
-            if (!A.live) break;
+        while (more) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                if (more) {
+                    UNET_NEXT(buf[(k + D - 1) % D])
+                    UNET_CONSUME(buf[k])
+                    more = buf[(k + 1) % D].live;
+                }
+            }
         }
     }
 #undef UNET_NEXT

@@ -577,26 +577,32 @@ int unet_csum(unet_ctx* c, const uint8_t* data, size_t len, uint16_t seed, uint1
     if (!c || !out || (!data && len)) return fail(UNET_E_INVAL, "null argument");
     if (len > kMaxLen) return fail(UNET_E_RANGE, "length %zu > 65535", len);
     HIP_TRY(hipSetDevice(c->device));
-    // one record, padded to a whole number of 16-byte chunks inside the pinned buffer
+    // one staging image [len u32 | seed u16 | pad to 16][record padded to whole chunks]: one copy in, one launch,
+    // one copy out, all on the compute stream
     const size_t padded = (len + 15) & ~(size_t)15;
+    const size_t total = 16 + (padded ? padded : 16);
     int rc;
-    if ((rc = ensure(c, c->d_arena, padded + 16))) return rc;
-    if ((rc = ensure(c, c->d_len, 16))) return rc;
-    if ((rc = ensure(c, c->d_out, 16))) return rc;
+    if ((rc = ensure(c, c->d_arena, total + 256))) return rc;
     HIP_TRY(hipEventSynchronize(c->pinned_free[0]));
+    HIP_TRY(hipEventSynchronize(c->pinned_free[1]));
     uint8_t* pin = (uint8_t*)c->pinned[0];
-    memset(pin, 0, padded + 32);
-    memcpy(pin, data, len);
-    u32 l32 = (u32)len;
-    memcpy(pin + padded, &l32, 4);
-    memcpy(pin + padded + 4, &seed, 2);
-    HIP_TRY(hipMemcpyAsync(c->d_arena.p, pin, padded ? padded : 16, hipMemcpyHostToDevice, c->s_comp));
-    HIP_TRY(hipMemcpyAsync(c->d_len.p, pin + padded, 8, hipMemcpyHostToDevice, c->s_comp));
-    HIP_TRY(hipEventRecord(c->pinned_free[0], c->s_comp));
-    rc = unet_csum_batch_dev(c, nullptr, (const uint8_t*)c->d_arena.p, padded ? padded : 16, nullptr, 1, (const u32*)c->d_len.p,
-                             (const uint16_t*)((const uint8_t*)c->d_len.p + 4), 1, (uint16_t*)c->d_out.p);
+    memset(pin, 0, total);
+    const u32 l32 = (u32)len;
+    memcpy(pin, &l32, 4);
+    memcpy(pin + 4, &seed, 2);
+    if (len) memcpy(pin + 16, data, len);
+    uint8_t* dev = (uint8_t*)c->d_arena.p;
+    HIP_TRY(hipMemcpyAsync(dev, pin, total, hipMemcpyHostToDevice, c->s_comp));
+    uint16_t* d_out = (uint16_t*)(dev + ((total + 255) & ~(size_t)255));
+    {
+        LenScope hint(c, (u32)len, (u32)len);
+        rc = unet_csum_batch_dev(c, nullptr, dev + 16, total - 16, nullptr, 1, (const u32*)dev, (const uint16_t*)(dev + 4), 1, d_out);
+    }
     if (rc) return rc;
-    return d2h_sync(c, out, c->d_out.p, 2);
+    HIP_TRY(hipMemcpyAsync(c->pinned[1], d_out, 2, hipMemcpyDeviceToHost, c->s_comp));
+    HIP_TRY(hipStreamSynchronize(c->s_comp));
+    memcpy(out, c->pinned[1], 2);
+    return UNET_OK;
 }
 
 /* ---------------------------------------------------------------- a2-a4 */
