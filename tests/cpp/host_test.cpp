@@ -44,7 +44,28 @@ static std::vector<uint8_t> icmp_message(uint8_t type, uint8_t code, uint32_t va
     return m;
 }
 
+// Longest-prefix match as in the reference's own router tests (src/protocols/ipv4.rs:440-491).
+static void router_tests() {
+    auto a = std::make_shared<Ipv4Interface>(Ipv4Address{0xC0000202}, Ipv4Address{0xFFFFFF00});
+    auto b = std::make_shared<Ipv4Interface>(Ipv4Address{0xC0000001}, Ipv4Address{0xFFFF0000});
+    Ipv4Router r;
+    CHECK(r.lookup(Ipv4Address{0xC0000203}) == nullptr);
+    r.register_route(Ipv4Address{0xC0000000}, b);
+    r.register_route(Ipv4Address{0xC0000200}, a);
+    const IpRoute* x = r.lookup(Ipv4Address{0xC0000203});
+    CHECK(x && x->interface == a && !x->next_hop);   // /24 beats /16
+    x = r.lookup(Ipv4Address{0xC0000303});
+    CHECK(x && x->interface == b);
+    CHECK(r.lookup(Ipv4Address{0x08080808}) == nullptr);
+    r.register_default(a, Ipv4Address{0xC0000201});
+    x = r.lookup(Ipv4Address{0x08080808});
+    CHECK(x && x->interface == a && x->next_hop && x->next_hop->v == 0xC0000201);
+    x = r.lookup(Ipv4Address{0xC0000203});
+    CHECK(x && !x->next_hop);                        // a more specific route still wins over the default
+}
+
 static void cpu_tests() {
+    router_tests();
     FrameArena a;
     const uint8_t x[40] = {1, 2, 3};
     CHECK(a.push(x, 0) == 0);
@@ -276,6 +297,101 @@ static void gpu_sharded_tests() {
     std::memcpy(l2.data() + 14, frames[7].data(), frames[7].size());
     CHECK(unet_flow_hash_record(l2.data(), l2.size(), UNET_MODE_L2) == unet_flow_hash_record(frames[7].data(), frames[7].size(), UNET_MODE_L3));
     CHECK(unet_flow_hash_record(l2.data(), 13, UNET_MODE_L2) == 0 && unet_flow_hash_record(frames[7].data(), 19, UNET_MODE_L3) == 0);
+
+    // the counters of the three contexts add up to the histogram of the merged verdicts
+    std::array<uint64_t, UNET_V_COUNT> hist{};
+    for (const unet_result& r : rep.results) hist[r.verdict]++;
+    CHECK(many.counters(true) == hist);
+    const std::array<uint64_t, UNET_V_COUNT> zero{};
+    CHECK(many.counters() == zero);
+
+    // transmit-side fill over the shards: blank the checksum fields of the UDP/ICMP packets, fill on three
+    // contexts, compare byte for byte with the oracle's fill of the same packets
+    std::vector<std::vector<uint8_t>> blank, want;
+    for (uint32_t i = 0; i < n && blank.size() < 2000; i++) {
+        std::vector<uint8_t> p = frames[i];
+        if (p.size() < 28 || (p[9] != 17 && p[9] != 1)) continue;
+        p[10] = p[11] = 0;
+        blank.push_back(p);
+        want.push_back(p);
+    }
+    std::vector<uint8_t> want_status(blank.size());
+    for (size_t i = 0; i < want.size(); i++) want_status[i] = oracle_generate(want[i].data(), want[i].size());
+    const std::vector<uint8_t> got_status = many.generate(blank);
+    CHECK(got_status == want_status);
+    CHECK(blank == want);
+    CHECK(blank.size() > 100);
+
+    // whole packets over the shards: same bytes as one context builds, and as the oracle builds
+    std::vector<std::vector<uint8_t>> payloads;
+    std::vector<unet_tx_desc> desc;
+    for (uint32_t i = 0; i < 1500; i++) {
+        const size_t plen = (i * 37u) % 1400u;
+        std::vector<uint8_t> pl(plen);
+        for (size_t k = 0; k < plen; k++) pl[k] = uint8_t(k * 7 + i);
+        unet_tx_desc d{};
+        d.src = ifc.unicast;
+        d.dst = 0xC0000200u | (i % 200u + 1u);
+        d.proto = i % 5 == 0 ? 1 : 17;
+        d.l4a = d.proto == 17 ? uint16_t(1000 + i % 50) : uint16_t(8 << 8);
+        d.l4b = uint16_t(2000 + i % 7);
+        d.values = 0x00010000u + i;
+        d.ip_id = uint16_t(i);
+        payloads.push_back(std::move(pl));
+        desc.push_back(d);
+    }
+    unet_iface tx_if = ifc;
+    tx_if.ext_tcp = 0;
+    std::vector<uint8_t> st_many;
+    const std::vector<std::vector<uint8_t>> built = many.tx_build(payloads, desc, tx_if, &st_many);
+    bool tx_same = built.size() == payloads.size();
+    oracle_iface toi{};
+    std::memcpy(&toi, &tx_if, sizeof toi);
+    for (size_t i = 0; i < built.size(); i++) {
+        oracle_tx_desc od{};
+        std::memcpy(&od, &desc[i], sizeof od);
+        std::vector<uint8_t> w(28 + payloads[i].size() + 64);
+        uint8_t st = 0;
+        w.resize(oracle_tx_build(&od, payloads[i].data(), payloads[i].size(), &toi, w.data(), &st));
+        tx_same &= st == 0 && st_many[i] == 0 && built[i] == w;
+    }
+    CHECK(tx_same);
+}
+
+// ipv4::send's routing step: a destination behind the default gateway is framed with the GATEWAY's MAC.
+static void gpu_routed_send_tests() {
+    Offload gpu(0);
+    auto tap = std::make_shared<Ipv4Interface>(Ipv4Address{0xC0000202}, Ipv4Address{0xFFFFFF00});
+    tap->mac = {0x02, 0xaa, 0xbb, 0xcc, 0xdd, 0xee};
+    auto lo = std::make_shared<Ipv4Interface>(Ipv4Address{0x7F000001}, Ipv4Address{0xFF000000});
+    lo->mtu = 65535;
+    Ipv4Router router;
+    router.register_route(Ipv4Address{0x7F000000}, lo);
+    router.register_route(Ipv4Address{0xC0000200}, tap);
+    router.register_default(tap, Ipv4Address{0xC0000201});
+    const MacAddress gw_mac = {0x02, 0x11, 0x22, 0x33, 0x44, 0x55}, peer_mac = {0x02, 0x66, 0x66, 0x66, 0x66, 0x66};
+    const ArpResolver arp = [&](Ipv4Address a) -> std::optional<MacAddress> {
+        if (a.v == 0xC0000201) return gw_mac;
+        if (a.v == 0xC0000209) return peer_mac;
+        return std::nullopt;
+    };
+    auto udp = [&](uint32_t dst, size_t n) {
+        TxRequest r;
+        r.proto = 17;
+        r.src = Endpoint{Ipv4Address{0}, 8000};
+        r.dst = Endpoint{Ipv4Address{dst}, 53};
+        r.data.assign(n, 0x42);
+        return r;
+    };
+    std::vector<TxRequest> reqs = {udp(0x08080808, 30), udp(0xC0000209, 31), udp(0xC0000277, 32)};
+    Ipv4IdGenerator ids;
+    const TxReport rep = send_batch_routed(gpu, router, ids, reqs, true, arp);
+    CHECK(rep.packets.size() == 2 && rep.unresolved == 1 && rep.errors.empty());
+    if (rep.packets.size() == 2) {
+        CHECK(std::memcmp(rep.packets[0].bytes.data(), gw_mac.data(), 6) == 0);    // off-subnet: the gateway's MAC
+        CHECK(be32(rep.packets[0].bytes.data() + 14 + 16) == 0x08080808);          // ... the real destination address
+        CHECK(std::memcmp(rep.packets[1].bytes.data(), peer_mac.data(), 6) == 0);  // on-subnet: the peer's own MAC
+    }
 }
 
 int main(int argc, char** argv) {
@@ -285,6 +401,7 @@ int main(int argc, char** argv) {
         gpu_tests();
         gpu_send_tests();
         gpu_sharded_tests();
+        gpu_routed_send_tests();
     }
     if (g_fail) {
         std::printf("%d check(s) failed\n", g_fail);

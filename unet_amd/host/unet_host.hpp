@@ -26,6 +26,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/unet_offload.h"
@@ -182,8 +183,10 @@ class Offload {
 
 // ---------------------------------------------------------------------------------------------
 // Several GPUs behind one call.  Frames are independent, so each goes to the GPU chosen by the hash of its
-// flow 5-tuple (all frames of a flow meet on one GPU; nothing is exchanged between GPUs); every GPU gets its
-// own arena and is driven by its own host thread, and the verdicts come back in the caller's order.
+// flow 5-tuple (all frames of a flow meet on one GPU; nothing is exchanged between GPUs).  The calling thread
+// only hashes; every GPU has a host thread of its own that packs that GPU's arena, runs the offload call and
+// scatters the answers back into the caller's order.  The per-verdict counters of all contexts are summed on
+// request (the only values that are ever combined across GPUs).
 class ShardedOffload {
   public:
     // One context per entry; a device id may appear more than once (several contexts on one GPU).
@@ -204,42 +207,122 @@ class ShardedOffload {
         std::vector<size_t> shard_sizes;
     };
     Report verify(const std::vector<std::vector<uint8_t>>& frames, const unet_iface& iface) {
-        const size_t n = frames.size(), g = gpus_.size();
+        const size_t n = frames.size();
         Report rep;
         rep.results.resize(n);
-        rep.shard.resize(n);
-        rep.shard_sizes.assign(g, 0);
-        std::vector<std::vector<size_t>> index(g);
-        for (auto& a : arenas_) a->clear();
+        place(n, rep.shard, rep.shard_sizes, [&](size_t i) { return shard_of(frames[i].data(), frames[i].size(), iface.mode, gpus_.size()); });
+        on_every_shard([&](size_t s) {
+            FrameArena& a = *arenas_[s];
+            a.clear();
+            for (size_t i : index_[s]) a.push(frames[i].data(), frames[i].size());
+            const std::vector<unet_result> part = gpus_[s]->verify(a, iface);
+            for (size_t k = 0; k < index_[s].size(); k++) rep.results[index_[s][k]] = part[k];
+        });
+        return rep;
+    }
+
+    // Transmit-side checksum fill (unet_generate) of L3 packets, in place in the caller's buffers; returns the
+    // per-packet status in input order.
+    std::vector<uint8_t> generate(std::vector<std::vector<uint8_t>>& packets) {
+        const size_t n = packets.size();
+        std::vector<uint8_t> status(n);
+        std::vector<uint32_t> shard;
+        std::vector<size_t> sizes;
+        place(n, shard, sizes, [&](size_t i) { return shard_of(packets[i].data(), packets[i].size(), UNET_MODE_L3, gpus_.size()); });
+        on_every_shard([&](size_t s) {
+            FrameArena& a = *arenas_[s];
+            a.clear();
+            for (size_t i : index_[s]) a.push(packets[i].data(), packets[i].size());
+            const std::vector<uint8_t> st = gpus_[s]->generate(a);
+            for (size_t k = 0; k < index_[s].size(); k++) {
+                const size_t i = index_[s][k];
+                status[i] = st[k];
+                if (!packets[i].empty()) std::memcpy(packets[i].data(), a.record(k), packets[i].size());
+            }
+        });
+        return status;
+    }
+
+    // Whole packets from payloads + descriptors (unet_tx_build), placed by the flow hash of the descriptor's
+    // 5-tuple.  Returns one vector per packet in input order (empty for a refused one).
+    std::vector<std::vector<uint8_t>> tx_build(const std::vector<std::vector<uint8_t>>& payloads, const std::vector<unet_tx_desc>& desc,
+                                               const unet_iface& iface, std::vector<uint8_t>* status_out = nullptr) {
+        const size_t n = payloads.size();
+        if (desc.size() != n) throw std::invalid_argument("one descriptor per payload");
+        std::vector<std::vector<uint8_t>> out(n);
+        std::vector<uint8_t> status(n);
+        std::vector<uint32_t> shard;
+        std::vector<size_t> sizes;
+        place(n, shard, sizes, [&](size_t i) {
+            const unet_tx_desc& d = desc[i];
+            const bool ports = d.proto == 17;
+            return static_cast<uint32_t>(unet_flow_hash5(iface.unicast, d.dst, d.proto, ports ? d.l4a : 0, ports ? d.l4b : 0) % gpus_.size());
+        });
+        on_every_shard([&](size_t s) {
+            FrameArena& a = *arenas_[s];
+            a.clear();
+            std::vector<unet_tx_desc> dd;
+            dd.reserve(index_[s].size());
+            for (size_t i : index_[s]) {
+                a.push(payloads[i].data(), payloads[i].size());
+                dd.push_back(desc[i]);
+            }
+            std::vector<uint8_t> st;
+            std::vector<std::vector<uint8_t>> built = gpus_[s]->tx_build(a, dd, iface, &st);
+            for (size_t k = 0; k < index_[s].size(); k++) {
+                out[index_[s][k]] = std::move(built[k]);
+                status[index_[s][k]] = st[k];
+            }
+        });
+        if (status_out) *status_out = std::move(status);
+        return out;
+    }
+
+    // Per-verdict counts of everything judged so far, summed over the GPUs (unet_counters_sum).
+    std::array<uint64_t, UNET_V_COUNT> counters(bool reset = false) {
+        std::vector<unet_ctx*> h;
+        for (auto& g : gpus_) h.push_back(g->get());
+        std::array<uint64_t, UNET_V_COUNT> out{};
+        if (unet_counters_sum(h.data(), static_cast<uint32_t>(h.size()), out.data(), reset ? 1 : 0) != UNET_OK)
+            throw std::runtime_error(std::string("unet_counters_sum: ") + unet_last_error());
+        return out;
+    }
+
+  private:
+    template <class ShardOf>
+    void place(size_t n, std::vector<uint32_t>& shard, std::vector<size_t>& sizes, ShardOf&& shard_of_item) {
+        const size_t g = gpus_.size();
+        shard.resize(n);
+        index_.assign(g, {});
         for (size_t i = 0; i < n; i++) {
-            const uint32_t s = shard_of(frames[i].data(), frames[i].size(), iface.mode, g);
-            rep.shard[i] = s;
-            arenas_[s]->push(frames[i].data(), frames[i].size());
-            index[s].push_back(i);
+            shard[i] = shard_of_item(i);
+            index_[shard[i]].push_back(i);
         }
-        std::vector<std::vector<unet_result>> part(g);
+        sizes.assign(g, 0);
+        for (size_t s = 0; s < g; s++) sizes[s] = index_[s].size();
+    }
+    // Runs work(s) for every shard on a thread of its own; the first failure is rethrown with its shard.
+    template <class Work>
+    void on_every_shard(Work&& work) {
+        const size_t g = gpus_.size();
         std::vector<std::string> err(g);
         std::vector<std::thread> th;
         for (size_t s = 0; s < g; s++)
             th.emplace_back([&, s] {
                 try {
-                    part[s] = gpus_[s]->verify(*arenas_[s], iface);
+                    work(s);
                 } catch (const std::exception& e) {
-                    err[s] = e.what();
+                    err[s] = e.what()[0] ? e.what() : "error";
                 }
             });
         for (auto& t : th) t.join();
-        for (size_t s = 0; s < g; s++) {
+        for (size_t s = 0; s < g; s++)
             if (!err[s].empty()) throw std::runtime_error("shard " + std::to_string(s) + ": " + err[s]);
-            rep.shard_sizes[s] = index[s].size();
-            for (size_t k = 0; k < index[s].size(); k++) rep.results[index[s][k]] = part[s][k];
-        }
-        return rep;
     }
 
-  private:
     std::vector<std::unique_ptr<Offload>> gpus_;
     std::vector<std::unique_ptr<FrameArena>> arenas_;
+    std::vector<std::vector<size_t>> index_;  // per shard: the input indices it owns, in input order
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -284,6 +367,33 @@ class UdpContext {
     std::array<std::optional<Pcb>, UDP_PCB_LENGTH> pcbs_{};
 };
 
+// Routing table: src/protocols/ipv4.rs:231-280.  Longest netmask wins among the routes whose network holds the
+// destination; a default route carries the gateway as next hop.
+struct IpRoute {
+    Ipv4Address network, netmask;
+    std::shared_ptr<Ipv4Interface> interface;
+    std::optional<Ipv4Address> next_hop;
+};
+class Ipv4Router {
+  public:
+    void register_route(Ipv4Address network, std::shared_ptr<Ipv4Interface> interface) {  // ipv4.rs:243-250
+        const Ipv4Address mask = interface->netmask;
+        routes_.push_back(IpRoute{network, mask, std::move(interface), std::nullopt});
+    }
+    void register_default(std::shared_ptr<Ipv4Interface> interface, Ipv4Address gateway) {  // ipv4.rs:252-259
+        routes_.push_front(IpRoute{Ipv4Address{Ipv4Address::ANY}, Ipv4Address{Ipv4Address::ANY}, std::move(interface), gateway});
+    }
+    const IpRoute* lookup(Ipv4Address dst) const {  // ipv4.rs:261-271
+        const IpRoute* candidate = nullptr;
+        for (const IpRoute& r : routes_)
+            if ((dst.v & r.netmask.v) == r.network.v && (!candidate || r.netmask.v > candidate->netmask.v)) candidate = &r;
+        return candidate;
+    }
+
+  private:
+    std::deque<IpRoute> routes_;
+};
+
 struct Ipv4IdGenerator {  // src/protocols/ipv4.rs:282-297
     uint16_t id = 0;
     uint16_t next() { return id++; }
@@ -326,7 +436,10 @@ class TxBatch {
     // udp::send's length check (udp.rs:174-180) and ipv4::send's checks (ipv4.rs:320-335); takes the next
     // identification only for a packet that will be built (ipv4.rs:337).  Returns false and reports why
     // when the reference would have bailed out.
-    bool add(const TxRequest& r, const Ipv4Interface& ifc, Ipv4IdGenerator& ids, bool l2, const ArpResolver& arp, TxReport& rep) {
+    // `next_hop`: the route's gateway when it has one; the ARP cache is asked for that address instead of the
+    // destination (ipv4.rs:346-353).
+    bool add(const TxRequest& r, const Ipv4Interface& ifc, Ipv4IdGenerator& ids, bool l2, const ArpResolver& arp, TxReport& rep,
+             std::optional<Ipv4Address> next_hop = std::nullopt) {
         constexpr size_t kIpv4PayloadMax = 65535 - 20;  // ipv4.rs:18-20
         if (r.proto == 17 && r.data.size() > kIpv4PayloadMax - 8) {
             rep.errors.push_back("udp packet too long, len: " + std::to_string(r.data.size()) + ", max: " + std::to_string(kIpv4PayloadMax - 8));
@@ -361,7 +474,7 @@ class TxBatch {
             if (dst == ifc.broadcast || dst.v == Ipv4Address::BROADCAST) {
                 std::memset(d.dst_mac, 0xff, 6);
             } else {
-                const std::optional<MacAddress> mac = arp ? arp(dst) : std::nullopt;
+                const std::optional<MacAddress> mac = arp ? arp(next_hop.value_or(dst)) : std::nullopt;
                 d.ip_id = ids.next();  // the reference has built the packet before it consults the ARP cache
                 if (!mac) {
                     rep.unresolved++;
@@ -408,6 +521,32 @@ inline TxReport send_batch(const Offload& gpu, const Ipv4Interface& ifc, Ipv4IdG
     TxBatch batch;
     for (const TxRequest& r : requests) batch.add(r, ifc, ids, l2, arp, rep);
     batch.flush(gpu, ifc, l2, rep);
+    return rep;
+}
+
+// ipv4::send's first step as well (ipv4.rs:307-309): the route picks the interface and the next hop.  One build
+// call per interface that got packets.
+inline TxReport send_batch_routed(const Offload& gpu, const Ipv4Router& router, Ipv4IdGenerator& ids, const std::vector<TxRequest>& requests,
+                                  bool l2 = false, const ArpResolver& arp = nullptr) {
+    TxReport rep;
+    std::vector<std::pair<const Ipv4Interface*, std::unique_ptr<TxBatch>>> batches;
+    for (const TxRequest& r : requests) {
+        const IpRoute* route = router.lookup(r.dst.address);
+        if (!route) {
+            rep.errors.push_back("no route found, dst: " + r.dst.address.to_string());
+            continue;
+        }
+        const Ipv4Interface* ifp = route->interface.get();
+        TxBatch* b = nullptr;
+        for (auto& kv : batches)
+            if (kv.first == ifp) b = kv.second.get();
+        if (!b) {
+            batches.emplace_back(ifp, std::make_unique<TxBatch>());
+            b = batches.back().second.get();
+        }
+        b->add(r, *ifp, ids, l2, arp, rep, route->next_hop);
+    }
+    for (auto& kv : batches) kv.second->flush(gpu, *kv.first, l2, rep);
     return rep;
 }
 
