@@ -46,6 +46,7 @@ WORKLOADS = {
     # name: (trace kind, records per GPU per batch, fixed stride in 16-byte slots or 0)
     "udp1500": (unet_amd.SYNTH_UDP1500, 1 << 22, 94),
     "imix": (unet_amd.SYNTH_IMIX, 1 << 23, 0),
+    "odd": (unet_amd.SYNTH_ODD, 1 << 23, 0),
     "hdr20": (unet_amd.SYNTH_IPV4_HDR20, 1 << 24, 0),
     "trace": (unet_amd.SYNTH_FLOWS, 1 << 24, 0),
     # the other entry points over the udp1500 batch
@@ -59,6 +60,7 @@ WORKLOADS = {
 DESCRIPTION = {
     "udp1500": "4,194,304 x 1500-byte IPv4/UDP packets per GPU (BASELINE configs[2])",
     "imix": "8,388,608 mixed 64-9000-byte TCP/UDP/ICMP packets per GPU (BASELINE configs[3])",
+    "odd": "8,388,608 mixed TCP/UDP/ICMP packets per GPU of 65 / 577 / 1499 / 4097 / 8999 bytes (odd lengths, one byte past or short of a 16-byte boundary)",
     "hdr20": "16,777,216 bare 20-byte IPv4 headers per GPU (BASELINE configs[1])",
     "trace": "flow-table trace (2^20 flows, IMIX sizes) generated in HBM in chunks of 16,777,216 records per GPU (BASELINE configs[4])",
     "csum": "calculate_checksum over 4,194,304 x 1500-byte records per GPU (unet_csum_batch_dev)",
@@ -295,7 +297,7 @@ class Batch:
                               self.status.data_ptr(), self.stream)
 
     def counts(self):
-        d_cnt = torch.zeros(32, dtype=torch.int64, device="cuda")
+        d_cnt = torch.zeros(unet_amd.V_COUNT, dtype=torch.int64, device="cuda")
         self.ctx.count_verdicts_dev(self.out.data_ptr(), self.n, d_cnt.data_ptr(), self.stream)
         return d_cnt
 
@@ -363,7 +365,7 @@ def main():
         stride16 = args.stride16
     if args.frames:
         n_per_gpu = args.frames
-    ext_tcp = (args.workload in ("imix", "trace")) if args.ext_tcp is None else bool(args.ext_tcp)
+    ext_tcp = (args.workload in ("imix", "trace", "odd")) if args.ext_tcp is None else bool(args.ext_tcp)
     ifc = unet_amd.Iface(ext_tcp=ext_tcp)
     ctx = unet_amd.Offload(local)
     # A dedicated torch stream: its raw handle goes to the C ABI, so the kernels, torch's own ops and the
@@ -385,7 +387,7 @@ def main():
         # chunk; only the verify launches are timed (inputs resident when each timed region starts).
         n_chunks = min(args.steps, max(1, args.total_frames // n_global))
         kernel_s, frames, alg_bytes_total = 0.0, 0, 0
-        total_cnt = torch.zeros(32, dtype=torch.int64, device="cuda")
+        total_cnt = torch.zeros(unet_amd.V_COUNT, dtype=torch.int64, device="cuda")
         sizes = []
         sync_all()
         t_all = time.perf_counter()

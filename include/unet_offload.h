@@ -62,7 +62,7 @@ enum unet_verdict {
     UNET_V_DROP_TCP_SHORT = 21,      /* segment < 20 B */
     UNET_V_DROP_TCP_DOFF = 22,       /* data offset < 5 or data offset*4 > segment length */
     UNET_V_DROP_TCP_CSUM = 23,       /* pseudo-header (protocol 6) checksum != 0 */
-    UNET_V_ACCEPT_TCP = 24,
+    UNET_V_ACCEPT_TCP = 24,          /* checksum good and options well-formed (else DROP_TCP_OPTION below) */
     /* Only produced by unet_ipv4_validate*: header parsed and validate() returned Ok. */
     UNET_V_L3_HEADER_OK = 25,
     /* ARP messages (ethertype 0x0806, MODE_L2), arp::recv src/protocols/arp.rs:206-246: */
@@ -72,7 +72,11 @@ enum unet_verdict {
     UNET_V_DROP_ARP_HLEN = 29,       /* hardware address length != 6, arp.rs:218-220 */
     UNET_V_DROP_ARP_PLEN = 30,       /* protocol address length != 4, arp.rs:221-223 */
     UNET_V_IGNORE_ARP_NOT_FOR_ME = 31,/* valid, target is another host: Ok(()) with no action, arp.rs:238,246 */
-    UNET_V_COUNT = 32                /* size of a counter array indexed by verdict */
+    /* Extension (ext_tcp = 1 only): the checksum verified, but the option area between byte 20 and the data offset
+     * is malformed -- an option without room for its length byte, a length below 2 or running past the data
+     * offset, or a wrong length for MSS (4), window scale (3), SACK permitted (2), SACK (2 + 8k) or timestamps (10). */
+    UNET_V_DROP_TCP_OPTION = 32,
+    UNET_V_COUNT = 40                /* size of a counter array indexed by verdict (33..39 are unassigned) */
 };
 
 /* Per-frame result, 4 bytes.
@@ -322,6 +326,7 @@ int unet_flow_hash_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint
 #define UNET_SYNTH_UDP1500 3    /* 1500-byte IPv4+UDP packets, stride16 = 94 */
 #define UNET_SYNTH_IMIX 4       /* mixed 64..9000-byte TCP/UDP/ICMP packets, packed at 16-byte boundaries */
 #define UNET_SYNTH_FLOWS 5      /* IMIX shapes whose 5-tuples come from a table of 2^20 flows of skewed popularity */
+#define UNET_SYNTH_ODD 6        /* the IMIX mix with lengths 65 / 577 / 1499 / 4097 / 8999: odd, and one past or short of a 16-byte boundary */
 
 /* Length of record idx (bytes) for a trace kind; pure function, host side. */
 uint32_t unet_synth_len(int kind, uint64_t seed, uint64_t idx);

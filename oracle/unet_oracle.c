@@ -160,6 +160,25 @@ static oracle_result udp_recv(const uint8_t* seg, size_t len, uint32_t src, uint
 
 /* TCP extension (nothing like it in the reference): same pseudo-header arithmetic with
  * protocol 6 and the buffer's segment length, plus the data-offset sanity check. */
+/* Option area of a TCP header (bytes 20 .. data offset): 1 when malformed.  No counterpart in the reference;
+ * lengths per RFC 9293 (MSS 4), RFC 7323 (window scale 3, timestamps 10), RFC 2018 (SACK permitted 2, SACK 2 + 8k). */
+static int tcp_options_malformed(const uint8_t* opt, uint32_t optlen) {
+    uint32_t pos = 0;
+    while (pos < optlen) {
+        uint32_t kind = opt[pos];
+        if (kind == 0) break;
+        if (kind == 1) { pos++; continue; }
+        if (pos + 1 >= optlen) return 1;
+        uint32_t l = opt[pos + 1];
+        if (l < 2 || pos + l > optlen) return 1;
+        if ((kind == 2 && l != 4) || (kind == 3 && l != 3) || (kind == 4 && l != 2) || (kind == 8 && l != 10) ||
+            (kind == 5 && (l < 10 || (l - 2) % 8 != 0)))
+            return 1;
+        pos += l;
+    }
+    return 0;
+}
+
 static oracle_result tcp_recv_ext(const uint8_t* seg, size_t len, uint32_t src, uint32_t dst) {
     if (len < 20) return mk(OV_DROP_TCP_SHORT, 6, 0);
     uint32_t doff = seg[12] >> 4;
@@ -173,6 +192,7 @@ static oracle_result tcp_recv_ext(const uint8_t* seg, size_t len, uint32_t src, 
     put_be16(pseudo + 10, (uint16_t)len);
     uint16_t fin = csum_of(pseudo, 12, (uint16_t)~sum);
     if (fin != 0) return mk(OV_DROP_TCP_CSUM, 6, fin);
+    if (tcp_options_malformed(seg + 20, doff * 4 - 20)) return mk(OV_DROP_TCP_OPTION, 6, 0);
     return mk(OV_ACCEPT_TCP, 6, 0);
 }
 

@@ -56,7 +56,8 @@ enum oracle_verdict {
     OV_DROP_ARP_HLEN = 29,
     OV_DROP_ARP_PLEN = 30,
     OV_IGNORE_ARP_NOT_FOR_ME = 31,
-    OV_COUNT = 32
+    OV_DROP_TCP_OPTION = 32, /* extension: checksum good, option area malformed */
+    OV_COUNT = 40
 };
 
 typedef struct oracle_result {

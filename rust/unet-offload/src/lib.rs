@@ -53,12 +53,13 @@ pub enum Verdict {
     DropArpHlen = 29,
     DropArpPlen = 30,
     IgnoreArpNotForMe = 31,
+    DropTcpOption = 32,
 }
 
 impl Verdict {
     pub fn from_code(code: u8) -> Option<Verdict> {
-        if code < sys::UNET_V_COUNT {
-            // SAFETY: the enum is repr(u8) and has a variant for every value below UNET_V_COUNT.
+        if code <= Verdict::DropTcpOption as u8 {
+            // SAFETY: the enum is repr(u8) and has a variant for every value from 0 to DropTcpOption.
             Some(unsafe { std::mem::transmute::<u8, Verdict>(code) })
         } else {
             None

@@ -43,7 +43,7 @@ V = dict(
     DROP_L3_PROTO=6, DROP_L3_VERSION=7, DROP_L3_IHL_SHORT=8, DROP_L3_IHL_LONG=9, DROP_L3_FRAGMENT=10,
     DROP_L3_CSUM=11, IGNORE_L3_NOT_FOR_ME=12, DROP_ICMP_TRUNCATED=13, DROP_ICMP_TYPE=14, ACCEPT_ICMP_ECHO=15,
     ACCEPT_ICMP_ECHOREPLY=16, DROP_UDP_SHORT=17, DROP_UDP_LEN=18, DROP_UDP_CSUM=19, ACCEPT_UDP=20,
-    DROP_TCP_SHORT=21, DROP_TCP_DOFF=22, DROP_TCP_CSUM=23, ACCEPT_TCP=24, L3_HEADER_OK=25,
+    DROP_TCP_SHORT=21, DROP_TCP_DOFF=22, DROP_TCP_CSUM=23, ACCEPT_TCP=24, L3_HEADER_OK=25, DROP_TCP_OPTION=32,
     DROP_ARP_TRUNCATED=26, DROP_ARP_HTYPE=27, DROP_ARP_PTYPE=28, DROP_ARP_HLEN=29, DROP_ARP_PLEN=30,
     IGNORE_ARP_NOT_FOR_ME=31)
 
@@ -110,7 +110,32 @@ def ipv4_recv(d: bytes, ifc):
         return ("DROP_TCP_DOFF", 6, 0)
     pseudo = d[12:20] + bytes([0, 6]) + struct.pack(">H", len(p))
     f = ck(pseudo, (~ck(p)) & 0xFFFF)
-    return ("DROP_TCP_CSUM", 6, f) if f else ("ACCEPT_TCP", 6, 0)
+    if f:
+        return ("DROP_TCP_CSUM", 6, f)
+    return ("DROP_TCP_OPTION", 6, 0) if tcp_options_bad(p[20:doff * 4]) else ("ACCEPT_TCP", 6, 0)
+
+
+FIXED_OPTION_LENGTH = {2: 4, 3: 3, 4: 2, 8: 10}  # MSS, window scale, SACK permitted, timestamps
+
+
+def tcp_options_bad(opts: bytes) -> bool:
+    """Extension, no counterpart in the reference: is the option area of a TCP header malformed?"""
+    while opts:
+        kind = opts[0]
+        if kind == 0:
+            return False
+        if kind == 1:
+            opts = opts[1:]
+            continue
+        if len(opts) < 2 or opts[1] < 2 or opts[1] > len(opts):
+            return True
+        n = opts[1]
+        if kind in FIXED_OPTION_LENGTH and n != FIXED_OPTION_LENGTH[kind]:
+            return True
+        if kind == 5 and (n < 10 or (n - 2) % 8):
+            return True
+        opts = opts[n:]
+    return False
 
 
 def arp_recv(d: bytes, ifc):
@@ -352,7 +377,28 @@ def main():
     tcp_ifc = dict(tap); tcp_ifc["ext_tcp"] = True
     tcp_ok = ip_header(6, other, me, 20 + 100) + tcp_segment(other, me, 443, 50000, pay)
     assert add("tcp_ext_ok", tcp_ok, tcp_ifc) == "ACCEPT_TCP"
-    assert add("tcp_ext_ok_options_odd", ip_header(6, other, me, 32 + 33) + tcp_segment(other, me, 443, 50000, pay[:33], doff=8, opts=prng("to", 12)), tcp_ifc) == "ACCEPT_TCP"
+    ts = bytes([1, 1, 8, 10]) + prng("to", 8)
+    assert add("tcp_ext_ok_options_odd", ip_header(6, other, me, 32 + 33) + tcp_segment(other, me, 443, 50000, pay[:33], doff=8, opts=ts), tcp_ifc) == "ACCEPT_TCP"
+
+    def tcp_opt(name, opts, want, payload=pay[:21]):
+        assert len(opts) % 4 == 0
+        pkt = ip_header(6, other, me, 20 + len(opts) + len(payload)) + tcp_segment(other, me, 443, 50000, payload, doff=5 + len(opts) // 4, opts=opts)
+        assert add(name, pkt, tcp_ifc) == want, name
+        return pkt
+    tcp_opt("tcp_opt_syn_typical", bytes([2, 4, 5, 0xb4, 4, 2, 8, 10]) + prng("t1", 8) + bytes([1, 3, 3, 7]), "ACCEPT_TCP")
+    tcp_opt("tcp_opt_all_nop", bytes([1] * 40), "ACCEPT_TCP")
+    tcp_opt("tcp_opt_eol_then_garbage", bytes([1, 0, 0xff, 0x01]), "ACCEPT_TCP")
+    tcp_opt("tcp_opt_sack_two_blocks", bytes([1, 1, 5, 18]) + prng("t2", 16), "ACCEPT_TCP")
+    tcp_opt("tcp_opt_unknown_kind_skipped", bytes([0xfd, 6, 1, 2, 3, 4, 1, 1]), "ACCEPT_TCP")
+    tcp_opt("tcp_opt_length_zero", bytes([8, 0, 0, 0]), "DROP_TCP_OPTION")
+    tcp_opt("tcp_opt_length_one", bytes([0x22, 1, 1, 1]), "DROP_TCP_OPTION")
+    tcp_opt("tcp_opt_no_room_for_length", bytes([1, 1, 1, 8]), "DROP_TCP_OPTION")
+    tcp_opt("tcp_opt_runs_past_data_offset", bytes([1, 1, 8, 10]) + prng("t3", 4), "DROP_TCP_OPTION")
+    tcp_opt("tcp_opt_mss_wrong_length", bytes([2, 6, 5, 0xb4, 0, 0, 1, 1]), "DROP_TCP_OPTION")
+    tcp_opt("tcp_opt_sack_wrong_length", bytes([5, 12]) + prng("t4", 10), "DROP_TCP_OPTION")
+    tcp_opt("tcp_opt_last_byte_kind", bytes([1] * 39 + [3]), "DROP_TCP_OPTION")
+    bad = bytearray(tcp_opt("tcp_opt_bad_and_bitflip_base", bytes([8, 0, 0, 0]), "DROP_TCP_OPTION")); bad[-1] ^= 1
+    assert add("tcp_opt_checksum_is_judged_first", bytes(bad), tcp_ifc) == "DROP_TCP_CSUM"
     b = bytearray(tcp_ok); b[77] ^= 0x80
     assert add("tcp_ext_bitflip", bytes(b), tcp_ifc) == "DROP_TCP_CSUM"
     assert add("tcp_ext_short", ip_header(6, other, me, 19) + bytes(19), tcp_ifc) == "DROP_TCP_SHORT"
@@ -371,6 +417,14 @@ def main():
     assert add("l2_min_frame_padding_breaks_udp_len", eth(mac, 0x0800, short_udp + bytes(46 - len(short_udp))), tap, l2=True) == "DROP_UDP_LEN"
     assert add("l2_icmp_echo_98", eth(mac, 0x0800, ip_header(1, 0xC0000201, me, 64) + echo), tap, l2=True) == "ACCEPT_ICMP_ECHO"
     assert add("l2_tcp_ext_ok", eth(mac, 0x0800, tcp_ok), tcp_ifc, l2=True) == "ACCEPT_TCP"
+    # TCP options that lie beyond the first 96 bytes of the record: IPv4 options (IHL 14) in front, 40 option bytes
+    deep_ok = bytes([1] * 26 + [8, 10]) + prng("d1", 8) + bytes([1, 1, 1, 0])
+    deep_bad = bytes([1] * 36 + [3, 4, 0, 0])  # window scale with length 4, at option bytes 36..39
+    for nm, opts, want in (("deep_ok", deep_ok, "ACCEPT_TCP"), ("deep_bad", deep_bad, "DROP_TCP_OPTION")):
+        seg = tcp_segment(other, me, 443, 50000, pay + pay, doff=15, opts=opts)
+        pkt = ip_header(6, other, me, len(seg), ihl=14, options=prng("opt14", 36)) + seg
+        assert add("tcp_opt_" + nm + "_l3", pkt, tcp_ifc) == want
+        assert add("tcp_opt_" + nm + "_l2", eth(mac, 0x0800, pkt), tcp_ifc, l2=True) == want
     assert add("l2_truncated_13", eth(mac, 0x0800, b"")[:13], tap, l2=True) == "DROP_L2_TRUNCATED"
     assert add("l2_ethertype_ipv6", eth(mac, 0x86DD, good_udp), tap, l2=True) == "DROP_L2_ETHERTYPE"
     assert add("l2_ethertype_checked_before_mac", eth(b"\x02\x01\x02\x03\x04\x05", 0x86DD, good_udp), tap, l2=True) == "DROP_L2_ETHERTYPE"

@@ -61,30 +61,30 @@ def test_context_counters_follow_every_host_pointer_call():
     lib = _ffi.load_library()
     with unet_amd.Offload(0) as ctx, unet_amd.Offload(0) as ctx2:
         assert not ctx.counters().any()
-        total = np.zeros(32, dtype=np.uint64)
+        total = np.zeros(unet_amd.V_COUNT, dtype=np.uint64)
         a, o, l = unet_amd.synth_host(unet_amd.SYNTH_IMIX, SEED, 0, 4000, ifc)
         r = ctx.verify(a, o, l, ifc)
-        total += np.bincount(r["verdict"], minlength=32).astype(np.uint64)
+        total += np.bincount(r["verdict"], minlength=unet_amd.V_COUNT).astype(np.uint64)
         r = ctx.verify_static(a, o, l, ifc)
-        total += np.bincount(r["verdict"], minlength=32).astype(np.uint64)
+        total += np.bincount(r["verdict"], minlength=unet_amd.V_COUNT).astype(np.uint64)
         t, out = ctx.verify_async(a, o, l, ifc)
         ctx.wait(t)
-        total += np.bincount(out["verdict"], minlength=32).astype(np.uint64)
+        total += np.bincount(out["verdict"], minlength=unet_amd.V_COUNT).astype(np.uint64)
         hdrs, _, _ = unet_amd.synth_host(unet_amd.SYNTH_IPV4_HDR20, SEED, 0, 5000, ifc)
         r = ctx.ipv4_validate(hdrs[:5000 * 20], ifc)
-        total += np.bincount(r["verdict"], minlength=32).astype(np.uint64)
+        total += np.bincount(r["verdict"], minlength=unet_amd.V_COUNT).astype(np.uint64)
         # a batch too large for one staging buffer takes the chunked path
         big_a, big_o, big_l = unet_amd.synth_host(unet_amd.SYNTH_UDP1500, SEED, 0, 30000, ifc)
         assert big_a.nbytes > (32 << 20)
         r = ctx.verify(big_a, big_o, big_l, ifc)
         assert np.array_equal(r, O.recv_batch(big_a, big_o, big_l, ifc))
-        total += np.bincount(r["verdict"], minlength=32).astype(np.uint64)
+        total += np.bincount(r["verdict"], minlength=unet_amd.V_COUNT).astype(np.uint64)
         assert np.array_equal(ctx.counters(), total)
         # a second context counts separately; the sum is the sum
         r2 = ctx2.verify(a, o, l, ifc)
-        c2 = np.bincount(r2["verdict"], minlength=32).astype(np.uint64)
+        c2 = np.bincount(r2["verdict"], minlength=unet_amd.V_COUNT).astype(np.uint64)
         assert np.array_equal(ctx2.counters(), c2)
-        both = np.zeros(32, dtype=np.uint64)
+        both = np.zeros(unet_amd.V_COUNT, dtype=np.uint64)
         handles = (C.c_void_p * 2)(ctx.h.value, ctx2.h.value)
         assert lib.unet_counters_sum(handles, 2, both.ctypes.data, 1) == 0
         assert np.array_equal(both, total + c2)

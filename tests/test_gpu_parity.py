@@ -226,7 +226,7 @@ def test_csum_batch_fixed_stride(offload):
 
 # ------------------------------------------------------------------ synthetic traces: device == host twin, GPU == oracle
 
-@pytest.mark.parametrize("kind,n", [(unet_amd.SYNTH_UDP1500, 3000), (unet_amd.SYNTH_IMIX, 20000), (unet_amd.SYNTH_FLOWS, 9000)])
+@pytest.mark.parametrize("kind,n", [(unet_amd.SYNTH_UDP1500, 3000), (unet_amd.SYNTH_IMIX, 20000), (unet_amd.SYNTH_FLOWS, 9000), (unet_amd.SYNTH_ODD, 20000)])
 @pytest.mark.parametrize("ext_tcp", [False, True])
 def test_trace_generator_and_verify(offload, kind, n, ext_tcp):
     torch = torch_mod()
@@ -246,10 +246,10 @@ def test_trace_generator_and_verify(offload, kind, n, ext_tcp):
     bad = np.nonzero(got != exp)[0]
     assert bad.size == 0, (bad[:5], got[bad[:5]], exp[bad[:5]], lens[bad[:5]])
     # histogram kernel
-    d_cnt = torch.zeros(32, dtype=torch.int64, device="cuda")
+    d_cnt = torch.zeros(unet_amd.V_COUNT, dtype=torch.int64, device="cuda")
     offload.count_verdicts_dev(d_out.data_ptr(), n, d_cnt.data_ptr(), stream())
     torch.cuda.synchronize()
-    assert d_cnt.cpu().numpy().tolist() == np.bincount(exp["verdict"], minlength=32).tolist()
+    assert d_cnt.cpu().numpy().tolist() == np.bincount(exp["verdict"], minlength=unet_amd.V_COUNT).tolist()
     # the host-pointer entry point gives the same answers
     got_h = offload.verify(h_arena, off16, lens, ifc)
     assert (got_h == exp).all()
@@ -547,7 +547,7 @@ def test_full_size_udp1500_batch_properties(offload):
     offload.synth_dev(unet_amd.SYNTH_UDP1500, SEED, 0, n, ifc, d_off.data_ptr(), d_len.data_ptr(), d_arena.data_ptr(), nbytes, stream())
     d_out = torch.zeros(n, dtype=torch.int32, device="cuda")
     offload.verify_dev(d_arena.data_ptr(), nbytes, None, stride16, d_len.data_ptr(), n, ifc, d_out.data_ptr(), stream())
-    d_cnt = torch.zeros(32, dtype=torch.int64, device="cuda")
+    d_cnt = torch.zeros(unet_amd.V_COUNT, dtype=torch.int64, device="cuda")
     offload.count_verdicts_dev(d_out.data_ptr(), n, d_cnt.data_ptr(), stream())
     torch.cuda.synchronize()
     cnt = d_cnt.cpu().numpy()
@@ -697,8 +697,8 @@ def test_flow_trace_chunks_every_record_against_oracle(offload):
     chunks = int(os.environ.get("UNET_TRACE_CHUNKS", "4"))
     n = 1 << 24
     ifc = unet_amd.Iface(ext_tcp=True)
-    total_gpu = torch.zeros(32, dtype=torch.int64, device="cuda")
-    total_cpu = np.zeros(32, dtype=np.int64)
+    total_gpu = torch.zeros(unet_amd.V_COUNT, dtype=torch.int64, device="cuda")
+    total_cpu = np.zeros(unet_amd.V_COUNT, dtype=np.int64)
     for c in range(chunks):
         first = c * n
         off16, lens, nbytes = unet_amd.synth_layout(unet_amd.SYNTH_FLOWS, SEED, first, n)
@@ -713,7 +713,7 @@ def test_flow_trace_chunks_every_record_against_oracle(offload):
         exp = oracle_over_device_arena(d_arena, off16, lens, ifc)
         bad = np.nonzero(got != exp)[0]
         assert bad.size == 0, (c, bad[:5], got[bad[:5]], exp[bad[:5]], lens[bad[:5]])
-        total_cpu += np.bincount(exp["verdict"], minlength=32)
+        total_cpu += np.bincount(exp["verdict"], minlength=unet_amd.V_COUNT)
         del d_arena, d_out, d_off, d_len
         print(f"chunk {c + 1}/{chunks}: {n} records identical", flush=True)
     assert total_gpu.cpu().numpy().tolist() == total_cpu.tolist() and total_cpu.sum() == chunks * n

@@ -40,7 +40,7 @@ def _worker(rank, world, port, mode, out_dir):
                                for o, l in zip(off16, lens)], dtype=np.uint32)
             mine = np.nonzero(shard.shard_of_hash(hashes, world) == rank)[0]
             res = O.recv_batch(arena, off16[mine], lens[mine], ifc)
-        counts = torch.from_numpy(np.bincount(res["verdict"], minlength=32).astype(np.int64))
+        counts = torch.from_numpy(np.bincount(res["verdict"], minlength=unet_amd.V_COUNT).astype(np.int64))
         local = counts.clone()
         shard.allreduce_counts(counts, dist)
         t = shard.max_over_ranks(1.0 + rank, "cpu", dist)
@@ -57,7 +57,7 @@ def test_two_ranks_cover_the_trace_and_counters_add_up(tmp_path, mode):
     r = [np.load(tmp_path / f"r{i}.npz") for i in range(world)]
     ifc = unet_amd.Iface(ext_tcp=True)
     arena, off16, lens = unet_amd.synth_host(unet_amd.SYNTH_IMIX, SEED, 0, N_PER_RANK * world, ifc)
-    exp = np.bincount(O.recv_batch(arena, off16, lens, ifc)["verdict"], minlength=32)
+    exp = np.bincount(O.recv_batch(arena, off16, lens, ifc)["verdict"], minlength=unet_amd.V_COUNT)
     # disjoint cover
     allidx = np.concatenate([x["mine"] for x in r])
     assert np.array_equal(np.sort(allidx), np.arange(N_PER_RANK * world))

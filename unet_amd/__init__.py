@@ -7,6 +7,7 @@ library is missing, ``load_library()`` raises.
 """
 from ._ffi import (  # noqa: F401
     RESULT_DTYPE,
+    V_COUNT,
     Iface,
     Offload,
     UnetError,
@@ -26,3 +27,4 @@ SYNTH_IPV4_HDR20 = 2
 SYNTH_UDP1500 = 3
 SYNTH_IMIX = 4
 SYNTH_FLOWS = 5
+SYNTH_ODD = 6

@@ -53,9 +53,10 @@ class Verdict(enum.IntEnum):
     DROP_ARP_HLEN = 29
     DROP_ARP_PLEN = 30
     IGNORE_ARP_NOT_FOR_ME = 31
+    DROP_TCP_OPTION = 32
 
 
-V_COUNT = 32
+V_COUNT = 40
 
 
 class _IfaceC(C.Structure):

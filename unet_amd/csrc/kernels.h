@@ -122,12 +122,20 @@ struct LdsFetch {
     const u32* w;
     __device__ __forceinline__ u32 operator()(u32 k) const { return w[k]; }
 };
+// Any dword of the lane's own record: out of LDS while it is parked there, from memory past that.
+struct DeepFetch {
+    const u32* w;     // LDS
+    const u32* g;     // the record in the arena
+    u32 lds_dwords;   // dwords of the record that LDS holds
+    __device__ __forceinline__ u32 operator()(u32 k) const { return k < lds_dwords ? w[k] : g[k]; }
+};
 
 struct Tile {
     u32 first, cnt, lane;
     u32 my_len, my_slot;
     bool my_ok;
-    const u32x4* my_hdr;  // set by tile_sums: where the lane's own record starts in LDS (at least its first six chunks)
+    const u32x4* my_hdr;  // set by the tile routes: where the lane's own record starts in LDS (at least its first six chunks)
+    u32 hdr_dwords;       // how many dwords of the record LDS holds there
     template <int TILE>
     __device__ __forceinline__ bool init(const Batch& b) {
         lane = threadIdx.x & 63u;
@@ -444,6 +452,7 @@ __device__ __forceinline__ u32 span_sums(const SpanPlan& sp, Tile& t, u32x4* __r
     const bool some = t.lane < t.cnt && my_nch != 0u;
     const u32x4* mine = park + (some ? t.my_slot - sp.base : 0u);
     t.my_hdr = mine;
+    t.hdr_dwords = 0xffffffffu;  // the whole record is staged
     const LaneTail tail(t.my_len);
     const bool partial = (t.my_len & 15u) != 0u;
     const u32 nfull = t.my_len >> 4;
@@ -477,6 +486,7 @@ __device__ __forceinline__ u32 tile_sums(const Batch& b, Tile& t, u32 pass, u32x
     const bool ok = t.my_ok && now;
     const u32 my_nch = ok ? (t.my_len + 15u) >> 4 : 0u;
     t.my_hdr = mine;
+    t.hdr_dwords = kHdrChunks * 4u;
     const bool my_small = ok && my_nch >= 1u && my_nch <= kSmallChunks;
     const bool my_mid = UNET_MID_PATH && ok && my_nch > kSmallChunks && my_nch <= kMidChunks;
     const bool my_row4 = my_mid && my_nch <= kRow4Chunks;
@@ -626,6 +636,7 @@ __device__ __forceinline__ u32 lane_loop_pass(const Batch& b, Tile& t, u32 pass,
     const bool now = t.lane < t.cnt && (TileGeom<TILE>::kPasses == 1u || t.lane / PASS == pass);
     *mine_now = now;
     t.my_hdr = mine;
+    t.hdr_dwords = kHdrChunks * 4u;
     const bool ok = t.my_ok && now;
     const u32 nch = ok ? (t.my_len + 15u) >> 4 : 0u;
     const u32 nfull = t.my_len >> 4;
@@ -727,7 +738,8 @@ __global__ __launch_bounds__(kBlock, (TILE == 64 ? UNET_OCC64 : 6) * (256 / UNET
         if (mine_now && t.my_ok) {
             LdsFetch f;
             f.w = reinterpret_cast<const u32*>(t.my_hdr);
-            const Parsed P = parse_record<MODE>(f, t.my_len, ifc);
+            const DeepFetch deep{f.w, reinterpret_cast<const u32*>(b.arena + (u64)t.my_slot * 16u), t.hdr_dwords};
+            const Parsed P = parse_record<MODE>(f, deep, t.my_len, ifc);
             res = P.kind == K_DONE ? P.res : finalize_record(P, total);
         }
     });

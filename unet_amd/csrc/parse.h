@@ -41,7 +41,8 @@ enum : u32 {
     V_DROP_ARP_HLEN = 29,
     V_DROP_ARP_PLEN = 30,
     V_IGNORE_ARP_NOT_FOR_ME = 31,
-    V_COUNT = 32
+    V_DROP_TCP_OPTION = 32,
+    V_COUNT = 40
 };
 
 constexpr int MODE_L3 = 0;
@@ -59,7 +60,28 @@ struct Parsed {
     u32 kind;
     u32 sub;
     u32 add;
+    u32 opt_bad;  // K_TCP: the option area is malformed (reported only if the checksum is good)
 };
+
+// TCP option area (extension; RFC 9293 3.1 / 3.2, RFC 7323, RFC 2018 lengths): `byte(i)` gives byte i of the
+// area, 0 <= i < optlen <= 40.  Returns 1 when it is malformed.
+template <class B>
+__device__ __forceinline__ u32 tcp_options_malformed(const B& byte, u32 optlen) {
+    u32 pos = 0;
+    while (pos < optlen) {
+        const u32 kind = byte(pos);
+        if (kind == 0u) break;  // end of option list: the rest is padding
+        if (kind == 1u) { pos += 1u; continue; }  // no-operation
+        if (pos + 1u >= optlen) return 1u;  // no room for the length byte
+        const u32 l = byte(pos + 1u);
+        if (l < 2u || pos + l > optlen) return 1u;
+        if ((kind == 2u && l != 4u) || (kind == 3u && l != 3u) || (kind == 4u && l != 2u) || (kind == 8u && l != 10u) ||
+            (kind == 5u && (l < 10u || ((l - 2u) & 7u) != 0u)))
+            return 1u;
+        pos += l;
+    }
+    return 0u;
+}
 
 // Ipv4Header::try_from (src/protocols/ipv4.rs:185-207) + validate (:128-157) on the five
 // little-endian dwords of the first 20 header bytes.  Returns the packed result.
@@ -92,12 +114,15 @@ __device__ __forceinline__ u32 l3raw(const F& f, u32 rel) {
     }
 }
 
-template <int MODE, class F>
-__device__ __forceinline__ Parsed parse_record(const F& f, u32 flen, const IfaceDev& ifc) {
+// `f(k)` = dword k of the record for the header bytes every check can reach within the first 96 bytes;
+// `deep(k)` the same for any dword inside the record (only the TCP option walk needs it).
+template <int MODE, class F, class D>
+__device__ __forceinline__ Parsed parse_record(const F& f, const D& deep, u32 flen, const IfaceDev& ifc) {
     Parsed P;
     P.kind = K_DONE;
     P.sub = 0;
     P.add = 0;
+    P.opt_bad = 0;
     u32 l3len = flen;
     u32 l2sum = 0;
     if (MODE == MODE_L2) {
@@ -179,6 +204,10 @@ __device__ __forceinline__ Parsed parse_record(const F& f, u32 flen, const Iface
     P.kind = K_TCP;
     P.sub = prefix;
     P.add = halves(w3) + halves(w4) + 0x0600u + bswap16(plen);
+    if (doff > 5u) {
+        const u32 at = (MODE == MODE_L2 ? 14u : 0u) + hl + 20u;  // record byte where the options start
+        P.opt_bad = tcp_options_malformed([&](u32 i) { const u32 b = at + i; return (deep(b >> 2) >> (8u * (b & 3u))) & 0xffu; }, doff * 4u - 20u);
+    }
     return P;
 }
 
@@ -186,7 +215,7 @@ __device__ __forceinline__ Parsed parse_record(const F& f, u32 flen, const Iface
 __device__ __forceinline__ u32 finalize_record(const Parsed& P, u32 total) {
     const u32 ck = finish(total - P.sub + P.add);
     if (P.kind == K_UDP) return ck != 0u ? pack_result(V_DROP_UDP_CSUM, 17, ck) : pack_result(V_ACCEPT_UDP, 17, 0);  // udp.rs:247-254
-    if (P.kind == K_TCP) return ck != 0u ? pack_result(V_DROP_TCP_CSUM, 6, ck) : pack_result(V_ACCEPT_TCP, 6, 0);
+    if (P.kind == K_TCP) return ck != 0u ? pack_result(V_DROP_TCP_CSUM, 6, ck) : pack_result(P.opt_bad ? V_DROP_TCP_OPTION : V_ACCEPT_TCP, 6, 0);
     return pack_result(V_ACCEPT_ICMP_ECHO, 1, ck);
 }
 

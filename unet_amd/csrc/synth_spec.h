@@ -32,6 +32,7 @@ constexpr int kKindHdr20 = 2;
 constexpr int kKindUdp1500 = 3;
 constexpr int kKindImix = 4;
 constexpr int kKindFlows = 5;  // IMIX shapes, but the 5-tuple comes from a table of 2^20 flows (skewed popularity)
+constexpr int kKindOdd = 6;    // IMIX rules with lengths that end one byte past or short of a 16-byte boundary, or odd
 constexpr u32 kFlowCount = 1u << 20;
 
 UNET_HD u64 fin(u64 z) {
@@ -64,6 +65,7 @@ constexpr u32 kFaultNotForMe = 21;   // IMIX: destination on another host
 constexpr u32 kFaultIhlLong = 27;    // IHL nibble 15
 constexpr u32 kFaultIcmpType = 29;   // IMIX, ICMP only: type 3
 constexpr u32 kFaultMoreFrag = 35;   // MF flag
+constexpr u32 kFaultTcpOpt = 45;     // IMIX, TCP with options only: malformed option area (checksum stays valid)
 constexpr u32 kFaultFragOff = 43;    // fragment offset != 0
 constexpr u32 kFaultProto = 51;      // protocol 47
 constexpr u32 kFaultIhlOpt = 59;     // HDR20: IHL 6..14 (valid: only 20 bytes are summed)
@@ -108,6 +110,7 @@ UNET_HD Shape shape_of(int kind, u64 seed, u64 idx) {
         u64 f6 = field(key, 6);
         u32 a = (u32)(f6 % 100);
         s.len = a < 56 ? 64u : (a < 88 ? 576u : (a < 96 ? 1500u : (a < 98 ? 4096u : 9000u)));
+        if (kind == kKindOdd) s.len = a < 56 ? 65u : (a < 88 ? 577u : (a < 96 ? 1499u : (a < 98 ? 4097u : 8999u)));
         u32 b = (u32)((f6 >> 8) % 100);
         s.proto = b < 88 ? 6u : (b < 98 ? 17u : 1u);
         if (kind == kKindFlows) s.proto = flow_proto(flow_key(seed, flow_id_of(key)));
@@ -195,7 +198,7 @@ UNET_HD u32 build_header(int kind, u64 key, const Shape& s, const Tuple& tp, u32
     const u64 f0 = field(key, 0), f3 = field(key, 3);
     const u64 f4 = field(key, 4), f5 = field(key, 5), f7 = field(key, 7), f8 = field(key, 8);
     const u32 hl = s.ihl * 4;
-    const bool imix = kind == kKindImix || kind == kKindFlows;
+    const bool imix = kind == kKindImix || kind == kKindFlows || kind == kKindOdd;
     // ---- IPv4 header
     u32 ihl_nibble = s.ihl, version = 4, proto = s.proto;
     u32 flags_frag = ((f0 >> 24) & 1) ? 0x4000u : 0u;
@@ -250,7 +253,22 @@ UNET_HD u32 build_header(int kind, u64 key, const Shape& s, const Tuple& tp, u32
         l4[13] = (uint8_t)(0x10 | (f8 & 0x0f));
         put16(l4 + 14, (u32)(f8 >> 8) & 0xffff);
         put16(l4 + 18, 0);
-        for (u32 i = 20; i < s.l4hl; i++) l4[i] = (uint8_t)(field(key, 9 + (i >> 3)) >> (8 * (i & 7)));
+        if (s.l4hl == 32) {
+            // 12 option bytes: NOP, NOP, timestamps (kind 8, length 10, two random 32-bit values)
+            const u64 ts = field(key, 9);
+            l4[20] = 1;
+            l4[21] = 1;
+            l4[22] = 8;
+            l4[23] = 10;
+            put32(l4 + 24, (u32)ts);
+            put32(l4 + 28, (u32)(ts >> 32));
+            if (imix && s.fault == kFaultTcpOpt) {
+                const u32 how = (u32)(field(key, 10) % 3);
+                if (how == 0) l4[23] = 1;        // length below 2
+                else if (how == 1) l4[23] = 11;  // runs past the data offset
+                else l4[22] = 2;                 // MSS with length 10
+            }
+        }
         csum_off = 16;
         pseudo = (tp.src >> 16) + (tp.src & 0xffff) + (dst >> 16) + (dst & 0xffff) + 6 + seglen;
     } else {

@@ -1059,7 +1059,7 @@ int unet_flow_hash_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint
 /* ---------------------------------------------------------------- synthetic traces */
 
 static bool kind_ok(int kind) {
-    return kind == UNET_SYNTH_IPV4_HDR20 || kind == UNET_SYNTH_UDP1500 || kind == UNET_SYNTH_IMIX || kind == UNET_SYNTH_FLOWS;
+    return kind == UNET_SYNTH_IPV4_HDR20 || kind == UNET_SYNTH_UDP1500 || kind == UNET_SYNTH_IMIX || kind == UNET_SYNTH_FLOWS || kind == UNET_SYNTH_ODD;
 }
 
 uint32_t unet_synth_len(int kind, uint64_t seed, uint64_t idx) {

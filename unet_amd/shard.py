@@ -16,7 +16,7 @@ from typing import Tuple
 import numpy as np
 import torch
 
-V_COUNT = 32
+V_COUNT = 40
 
 
 def rank_index_range(rank: int, world: int, frames_per_gpu: int) -> Tuple[int, int]:
@@ -40,7 +40,7 @@ def shard_skew(shards: np.ndarray, world: int) -> float:
 def allreduce_counts(counts: torch.Tensor, dist=None) -> torch.Tensor:
     """Sum the V_COUNT verdict counters over all ranks (in place); no-op without a process group."""
     if counts.numel() != V_COUNT or counts.dtype != torch.int64:
-        raise ValueError("expected 32 int64 counters")
+        raise ValueError(f"expected {V_COUNT} int64 counters")
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     return counts
