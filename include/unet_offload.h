@@ -301,6 +301,46 @@ int unet_count_verdicts_dev(unet_ctx* ctx, void* stream, const unet_result* d_re
 int unet_counters(unet_ctx* ctx, uint64_t* out /* UNET_V_COUNT */, int reset);
 int unet_counters_sum(unet_ctx* const* ctxs, uint32_t n_ctx, uint64_t* out /* UNET_V_COUNT */, int reset);
 
+/* ------------------------------------------- per-flow TCP tracking (extension) */
+/* No counterpart in the reference (it has no TCP, src/transport.rs:10-28); works on records unet_verify* has
+ * judged UNET_V_ACCEPT_TCP with iface.ext_tcp = 1.  A flow is one direction of a connection (its 5-tuple).  The
+ * table lives in device memory on the GPU that owns the flow -- flows are placed on GPUs by unet_flow_hash5 %
+ * n_gpus, so all segments of a flow meet the same table and nothing about it ever crosses GPUs.  It is
+ * direct-mapped: a flow whose slot holds another flow takes the slot over. */
+typedef struct unet_tcp_flow {   /* one table slot, 32 bytes; all zero = free */
+    uint32_t src;
+    uint32_t dst;
+    uint32_t ports;              /* source port << 16 | destination port */
+    uint32_t next_seq;           /* sequence number expected next */
+    uint32_t state;              /* UNET_TCP_* */
+    uint32_t segments;           /* segments seen since the flow took the slot */
+    uint32_t out_of_order;       /* of those: sequence number not the expected one */
+    uint32_t after_close;        /* of those: arrived after a reset */
+} unet_tcp_flow;
+#define UNET_TCP_FREE 0u
+#define UNET_TCP_SYN 1u          /* SYN seen, nothing after it yet */
+#define UNET_TCP_ESTABLISHED 2u
+#define UNET_TCP_FIN 3u          /* FIN seen in order */
+#define UNET_TCP_RESET 4u        /* RST seen; only a new SYN reopens the flow */
+/* per-segment outcome, one byte per record */
+#define UNET_TCPS_NOT_TCP 0u     /* not an accepted TCP segment: the table is not touched */
+#define UNET_TCPS_NEW 1u         /* first segment of its flow in the slot (free slot, take-over, or SYN after a reset) */
+#define UNET_TCPS_IN_ORDER 2u    /* sequence number = the expected one */
+#define UNET_TCPS_OUT_OF_ORDER 3u/* a gap (expectation moves past it) or old data (expectation unchanged) */
+#define UNET_TCPS_AFTER_CLOSE 4u /* segment of a reset flow */
+/* Applies the records of a batch to the table IN RECORD ORDER per flow (record i before record j > i) and writes
+ * each record's outcome to d_seg_state[i].  d_results are the verdicts unet_verify_dev wrote for the same batch
+ * (same iface mode).  table_slots must be a power of two (1 .. 2^30); the caller zeroes a new table.  The
+ * library's own workspace (about 40 bytes per record) grows on demand, so this call may allocate; it is
+ * enqueued on `stream` like every *_dev call. */
+int unet_tcp_track_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_t arena_bytes,
+                       const uint32_t* d_off16, uint32_t stride16, const uint32_t* d_len,
+                       const unet_result* d_results, uint32_t n, const unet_iface* iface,
+                       unet_tcp_flow* d_table, uint32_t table_slots, uint8_t* d_seg_state);
+/* Table slot a flow uses: a mix of unet_flow_hash5(src, dst, 6, sport, dport) independent of the bits that chose
+ * the GPU.  Host code. */
+uint32_t unet_tcp_slot(uint32_t src, uint32_t dst, uint16_t sport, uint16_t dport, uint32_t table_slots);
+
 /* --------------------------------------------------- flow-hash sharding */
 /* Build-defined 32-bit mix of the 5-tuple (ports are 0 unless protocol is UDP, or TCP
  * with ext_tcp): the shard of a frame is hash % n_gpus, so a flow stays on one GPU.

@@ -73,6 +73,10 @@ def lib():
         L.oracle_flow_hash5.argtypes = [C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint16, C.c_uint16]
         L.oracle_flow_hash_record.restype = C.c_uint32
         L.oracle_flow_hash_record.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(IfaceC)]
+        L.oracle_tcp_track.restype = None
+        L.oracle_tcp_track.argtypes = [vp, vp, C.c_uint32, vp, vp, C.c_uint32, C.POINTER(IfaceC), vp, C.c_uint32, vp]
+        L.oracle_tcp_slot.restype = C.c_uint32
+        L.oracle_tcp_slot.argtypes = [C.c_uint32, C.c_uint32, C.c_uint16, C.c_uint16, C.c_uint32]
         _lib = L
     return _lib
 
@@ -205,3 +209,27 @@ def flow_hash_record(rec: bytes, iface) -> int:
     rec = bytes(rec)
     ic = iface_c(iface)
     return int(lib().oracle_flow_hash_record(rec, len(rec), C.byref(ic)))
+
+
+TCP_FLOW_DTYPE = np.dtype([("src", "<u4"), ("dst", "<u4"), ("ports", "<u4"), ("next_seq", "<u4"), ("state", "<u4"), ("segments", "<u4"),
+                           ("out_of_order", "<u4"), ("after_close", "<u4")])
+
+
+def tcp_track(arena: np.ndarray, off16, lens: np.ndarray, results: np.ndarray, iface, table: np.ndarray, stride16: int = 0) -> np.ndarray:
+    """Sequential per-flow TCP tracking (extension): updates `table` (TCP_FLOW_DTYPE, power-of-two length) in place and
+    returns the per-record segment states."""
+    arena = np.ascontiguousarray(arena, dtype=np.uint8)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    if off16 is not None:
+        off16 = np.ascontiguousarray(off16, dtype=np.uint32)
+    results = np.ascontiguousarray(results)
+    assert table.dtype == TCP_FLOW_DTYPE and table.flags.c_contiguous
+    out = np.zeros(len(lens), dtype=np.uint8)
+    ic = iface_c(iface)
+    lib().oracle_tcp_track(arena.ctypes.data, None if off16 is None else off16.ctypes.data, stride16, lens.ctypes.data,
+                           results.ctypes.data, len(lens), C.byref(ic), table.ctypes.data, len(table), out.ctypes.data)
+    return out
+
+
+def tcp_slot(src, dst, sport, dport, slots) -> int:
+    return int(lib().oracle_tcp_slot(src, dst, sport, dport, slots))

@@ -508,3 +508,55 @@ uint32_t oracle_flow_hash_record(const uint8_t* rec, size_t len, const oracle_if
     }
     return oracle_flow_hash5(be32(rec + 12), be32(rec + 16), proto, sport, dport);
 }
+
+/* ------------------------------------------------------------ per-flow TCP tracking (extension) */
+
+uint32_t oracle_tcp_slot(uint32_t src, uint32_t dst, uint16_t sport, uint16_t dport, uint32_t table_slots) {
+    uint32_t l = 0;
+    while ((1u << l) < table_slots) l++;
+    if (l == 0) return 0;
+    return (uint32_t)(oracle_flow_hash5(src, dst, 6, sport, dport) * 0x9E3779B1u) >> (32 - l);
+}
+
+void oracle_tcp_track(const uint8_t* arena, const uint32_t* off16, uint32_t stride16, const uint32_t* len,
+                      const oracle_result* results, uint32_t n, const oracle_iface* iface, oracle_tcp_flow* table,
+                      uint32_t table_slots, uint8_t* seg_state) {
+    enum { FREE = 0, SYN = 1, EST = 2, FIN = 3, RESET = 4 };
+    for (uint32_t i = 0; i < n; i++) {
+        seg_state[i] = 0;
+        if (results[i].verdict != OV_ACCEPT_TCP) continue;
+        const uint8_t* d = arena + (size_t)(off16 ? off16[i] : (uint64_t)i * stride16) * 16;
+        size_t l3len = len[i];
+        if (iface->mode == 1) { d += 14; l3len -= 14; }
+        size_t hl = (size_t)(d[0] & 0x0f) * 4;
+        const uint8_t* t = d + hl;
+        uint32_t src = be32(d + 12), dst = be32(d + 16);
+        uint16_t sport = be16(t), dport = be16(t + 2);
+        uint32_t seq = be32(t + 4), doff = t[12] >> 4, flags = t[13];
+        uint32_t consumed = (uint32_t)(l3len - hl - doff * 4) + ((flags & 2) ? 1 : 0) + ((flags & 1) ? 1 : 0);
+        uint32_t ports = ((uint32_t)sport << 16) | dport;
+        oracle_tcp_flow* f = &table[oracle_tcp_slot(src, dst, sport, dport, table_slots)];
+        int same = f->state != FREE && f->src == src && f->dst == dst && f->ports == ports;
+        if (!same || (f->state == RESET && (flags & 2))) {
+            f->src = src; f->dst = dst; f->ports = ports;
+            f->next_seq = seq + consumed;
+            f->state = (flags & 4) ? RESET : ((flags & 1) ? FIN : ((flags & 2) ? SYN : EST));
+            f->segments = 1; f->out_of_order = 0; f->after_close = 0;
+            seg_state[i] = 1;
+            continue;
+        }
+        f->segments++;
+        if (f->state == RESET) { f->after_close++; seg_state[i] = 4; continue; }
+        if (seq == f->next_seq) {
+            seg_state[i] = 2;
+            f->next_seq = seq + consumed;
+            if (flags & 1) f->state = FIN;
+            else if (f->state == SYN && !(flags & 2)) f->state = EST;
+        } else {
+            seg_state[i] = 3;
+            f->out_of_order++;
+            if ((int32_t)(seq - f->next_seq) > 0) f->next_seq = seq + consumed;
+        }
+        if (flags & 4) f->state = RESET;
+    }
+}

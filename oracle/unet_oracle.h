@@ -138,6 +138,17 @@ void oracle_generate_batch(uint8_t* arena, const uint32_t* off16, uint32_t strid
                            uint32_t n, uint8_t* status);
 
 /* Build-defined flow hash (no reference counterpart; parity unpinned). */
+/* Per-flow TCP tracking (extension of this build, nothing like it in the reference): the sequential definition.
+ * Records are visited in index order; those with results[i].verdict == OV_ACCEPT_TCP update the direct-mapped
+ * table (table_slots a power of two, 32-byte slots laid out like unet_tcp_flow) and get a per-segment state. */
+typedef struct oracle_tcp_flow {
+    uint32_t src, dst, ports, next_seq, state, segments, out_of_order, after_close;
+} oracle_tcp_flow;
+void oracle_tcp_track(const uint8_t* arena, const uint32_t* off16, uint32_t stride16, const uint32_t* len,
+                      const oracle_result* results, uint32_t n, const oracle_iface* iface, oracle_tcp_flow* table,
+                      uint32_t table_slots, uint8_t* seg_state);
+uint32_t oracle_tcp_slot(uint32_t src, uint32_t dst, uint16_t sport, uint16_t dport, uint32_t table_slots);
+
 uint32_t oracle_flow_hash5(uint32_t src, uint32_t dst, uint8_t proto, uint16_t sport, uint16_t dport);
 uint32_t oracle_flow_hash_record(const uint8_t* rec, size_t len, const oracle_iface* iface);
 

@@ -111,6 +111,12 @@ TX_DESC_DTYPE = np.dtype([("src", "<u4"), ("dst", "<u4"), ("l4a", "<u2"), ("l4b"
                           ("proto", "u1"), ("reserved0", "u1"), ("dst_mac", "u1", (6,)), ("reserved1", "u1", (2,))])
 TX_OK, TX_E_PROTO, TX_E_TOO_LONG, TX_E_RANGE = 0, 1, 2, 3
 
+# unet_tcp_flow, 32 bytes
+TCP_FLOW_DTYPE = np.dtype([("src", "<u4"), ("dst", "<u4"), ("ports", "<u4"), ("next_seq", "<u4"), ("state", "<u4"), ("segments", "<u4"),
+                           ("out_of_order", "<u4"), ("after_close", "<u4")])
+TCP_FREE, TCP_SYN, TCP_ESTABLISHED, TCP_FIN, TCP_RESET = 0, 1, 2, 3, 4
+TCPS_NOT_TCP, TCPS_NEW, TCPS_IN_ORDER, TCPS_OUT_OF_ORDER, TCPS_AFTER_CLOSE = 0, 1, 2, 3, 4
+
 
 def tx_frame_len(payload_len, mode: int):
     """Length of the packet unet_tx_build_dev writes for a payload: 28 + payload in L3 mode; in L2 mode the
@@ -159,6 +165,8 @@ _SIGS = {
     "unet_tx_build": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, _vp, C.c_uint32, C.POINTER(_IfaceC), _u8p, C.c_uint64,
                                 _u32p, _u32p, _u8p]),
     "unet_count_verdicts_dev": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _u64p]),
+    "unet_tcp_track_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, _vp, C.c_uint32, C.POINTER(_IfaceC), _vp, C.c_uint32, _u8p]),
+    "unet_tcp_slot": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint16, C.c_uint16, C.c_uint32]),
     "unet_flow_hash5": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint16, C.c_uint16]),
     "unet_flow_hash_record": (C.c_uint32, [C.c_char_p, C.c_size_t, C.c_int]),
     "unet_flow_hash_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _u32p]),
@@ -517,6 +525,12 @@ class Offload:
 
     def count_verdicts_dev(self, d_results, n, d_counts, stream=None):
         _check(self.lib.unet_count_verdicts_dev(self.h, stream, d_results, n, d_counts))
+
+    def tcp_track_dev(self, d_arena, arena_bytes, d_off16, stride16, d_len, d_results, n, iface: Iface, d_table, table_slots, d_seg_state,
+                      stream=None):
+        ic = iface.c()
+        _check(self.lib.unet_tcp_track_dev(self.h, stream, d_arena, arena_bytes, d_off16, stride16, d_len, d_results, n, C.byref(ic), d_table,
+                                           table_slots, d_seg_state))
 
     def flow_hash_dev(self, d_arena, arena_bytes, d_off16, stride16, d_len, n, iface: Iface, d_hash, stream=None):
         ic = iface.c()

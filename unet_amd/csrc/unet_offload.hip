@@ -17,6 +17,9 @@
 
 #include "kernels.h"
 #include "pcap.h"
+#include "tcp_track.h"
+
+#include <hipcub/hipcub.hpp>
 
 using namespace unetdev;
 
@@ -33,6 +36,7 @@ static_assert(sizeof(unet_tx_fields) == 4 && offsetof(unet_tx_fields, l4_csum) =
 static_assert(sizeof(unet_pcap_info) == 48 && offsetof(unet_pcap_info, nanosecond) == 28 && offsetof(unet_pcap_info, arena_bytes) == 32 &&
               offsetof(unet_pcap_info, trailing_bytes) == 40, "unet_pcap_info layout");
 static_assert(sizeof(unet_ticket) == 4, "unet_ticket layout");
+static_assert(sizeof(unet_tcp_flow) == 32 && offsetof(unet_tcp_flow, next_seq) == 12 && offsetof(unet_tcp_flow, after_close) == 28, "unet_tcp_flow layout");
 static_assert((int)UNET_V_COUNT == (int)V_COUNT, "verdict tables out of sync");
 static_assert((int)UNET_V_L3_HEADER_OK == (int)V_L3_HEADER_OK, "verdict tables out of sync");
 static_assert((int)UNET_V_ACCEPT_UDP == (int)V_ACCEPT_UDP, "verdict tables out of sync");
@@ -173,7 +177,7 @@ struct unet_ctx {
     void* pinned[2] = {nullptr, nullptr};
     hipEvent_t pinned_free[2] = {nullptr, nullptr};
     hipEvent_t copied = nullptr;
-    DevBuf d_arena, d_off, d_len, d_out, d_aux, d_tx, d_tx_tab;
+    DevBuf d_arena, d_off, d_len, d_out, d_aux, d_tx, d_tx_tab, d_tcp;
     CopyPool* pool = nullptr;
     int tile_override = 0;        // UNET_TILE, read once at unet_open
     int tx_tile_override = 0;     // UNET_TX_TILE (4, 8, 16, 32, 64), read once at unet_open
@@ -494,7 +498,7 @@ void unet_close(unet_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->s_comp) (void)hipStreamSynchronize(c->s_comp);
     if (c->s_copy) (void)hipStreamSynchronize(c->s_copy);
-    DevBuf* bufs[] = {&c->d_arena, &c->d_off, &c->d_len, &c->d_out, &c->d_aux, &c->d_tx, &c->d_tx_tab};
+    DevBuf* bufs[] = {&c->d_arena, &c->d_off, &c->d_len, &c->d_out, &c->d_aux, &c->d_tx, &c->d_tx_tab, &c->d_tcp};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < 2; i++) {
@@ -1009,6 +1013,61 @@ int unet_counters_sum(unet_ctx* const* ctxs, uint32_t n_ctx, uint64_t* out, int 
         if (rc) return rc;
         for (u32 v = 0; v < UNET_V_COUNT; v++) out[v] += one[v];
     }
+    return UNET_OK;
+}
+
+/* ---------------------------------------------------------------- per-flow TCP tracking (extension) */
+
+static_assert(sizeof(unet_tcp_flow) == sizeof(TcpFlow), "flow table slot layout");
+static_assert(UNET_TCP_RESET == TCP_RESET && UNET_TCPS_AFTER_CLOSE == TCPS_AFTER_CLOSE && UNET_TCP_FIN == TCP_FIN, "tcp codes");
+
+static int log2_exact(uint32_t v) {
+    if (v == 0 || (v & (v - 1)) != 0) return -1;
+    int l = 0;
+    while ((1u << l) != v) l++;
+    return l;
+}
+
+uint32_t unet_tcp_slot(uint32_t src, uint32_t dst, uint16_t sport, uint16_t dport, uint32_t table_slots) {
+    const int l = log2_exact(table_slots);
+    if (l < 0) return 0;
+    return tcp_slot(flow_hash5(src, dst, 6u, sport, dport), (u32)l);
+}
+
+int unet_tcp_track_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_t arena_bytes, const uint32_t* d_off16,
+                       uint32_t stride16, const uint32_t* d_len, const unet_result* d_results, uint32_t n, const unet_iface* iface,
+                       unet_tcp_flow* d_table, uint32_t table_slots, uint8_t* d_seg_state) {
+    int rc = check_batch(ctx, d_arena, d_off16, stride16, d_len, n);
+    if (rc) return rc;
+    if (n == 0) return UNET_OK;
+    if (!d_results || !iface || !d_table || !d_seg_state) return fail(UNET_E_INVAL, "null argument");
+    if (iface->mode != UNET_MODE_L3 && iface->mode != UNET_MODE_L2) return fail(UNET_E_INVAL, "bad iface mode %d", iface->mode);
+    const int l2s = log2_exact(table_slots);
+    if (l2s < 0 || l2s > 30) return fail(UNET_E_INVAL, "table_slots must be a power of two up to 2^30, got %u", table_slots);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = pick(ctx, stream);
+    // workspace: keys and indices (in and out of the sort), the extracted segments, the sort's own scratch
+    size_t sort_bytes = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const u32*)nullptr, (u32*)nullptr, (const u32*)nullptr, (u32*)nullptr, (int)n, 0,
+                                               l2s + 1, s));
+    const size_t a4 = ((size_t)n * 4u + 255u) & ~(size_t)255u, aseg = ((size_t)n * sizeof(TcpSeg) + 255u) & ~(size_t)255u;
+    if ((rc = ensure(ctx, ctx->d_tcp, 4u * a4 + aseg + sort_bytes + 256u))) return rc;
+    uint8_t* w = (uint8_t*)ctx->d_tcp.p;
+    u32 *keys_in = (u32*)w, *keys_out = (u32*)(w + a4), *idx_in = (u32*)(w + 2u * a4), *idx_out = (u32*)(w + 3u * a4);
+    TcpSeg* segs = (TcpSeg*)(w + 4u * a4);
+    void* sort_tmp = w + 4u * a4 + aseg;
+    Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
+    const u32 grid = (n + kBlock - 1) / kBlock;
+    if (iface->mode == UNET_MODE_L2)
+        hipLaunchKernelGGL(k_tcp_keys<MODE_L2>, dim3(grid), dim3(kBlock), 0, s, b, (const u32*)d_results, (u32)l2s, keys_in, idx_in, segs, d_seg_state);
+    else
+        hipLaunchKernelGGL(k_tcp_keys<MODE_L3>, dim3(grid), dim3(kBlock), 0, s, b, (const u32*)d_results, (u32)l2s, keys_in, idx_in, segs, d_seg_state);
+    HIP_TRY(hipGetLastError());
+    // radix sort is stable: records of one slot stay in index order
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, (const u32*)keys_in, keys_out, (const u32*)idx_in, idx_out, (int)n, 0, l2s + 1, s));
+    hipLaunchKernelGGL(k_tcp_apply, dim3(grid), dim3(kBlock), 0, s, (const u32*)keys_out, (const u32*)idx_out, (const TcpSeg*)segs, n, (u32)l2s,
+                       (TcpFlow*)d_table, d_seg_state);
+    HIP_TRY(hipGetLastError());
     return UNET_OK;
 }
 
