@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Copies what tools/profile_all.sh left under gpurun_out/profile/ into profiles/<round>/ and rebuilds
-profiles/traffic.json (the per-launch HBM bytes bench.py reports as roofline.traffic).
-usage: tools/collect_profiles.py r1"""
+"""Copies what `tools/profile_all.sh <tag>` left under gpurun_out/profile_<tag>/ into profiles/<tag>/ and rebuilds
+profiles/traffic.json (the per-launch HBM bytes bench.py reports as roofline.traffic, each tied to the digest of
+the kernel sources the passes ran on).  Source and destination are both named by the tag, so a later round can
+never pick up an older round's files; a file is only replaced by a newer one.
+usage: tools/collect_profiles.py <tag>"""
 import csv
 import json
 import os
@@ -9,17 +11,34 @@ import shutil
 import subprocess
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r1"
-P, D = "gpurun_out/profile", os.path.join("profiles", rnd)
+tag = sys.argv[1]
+P, D = f"gpurun_out/profile_{tag}", os.path.join("profiles", tag)
 os.makedirs(D, exist_ok=True)
-kern = {"udp1500": "k_verify", "imix": "k_verify", "hdr20": "k_ipv4_validate_rows", "csum": "k_csum", "generate": "k_generate",
+
+
+def put(src, dst):
+    """copy unless the destination is newer than the source"""
+    if not os.path.exists(src):
+        return False
+    if os.path.exists(dst) and os.path.getmtime(dst) > os.path.getmtime(src):
+        print(f"kept {dst}: newer than {src}")
+        return False
+    shutil.copy2(src, dst)
+    return True
+
+
+kern = {"udp1500": "k_verify", "imix": "k_verify", "odd": "k_verify", "hdr20": "k_ipv4_validate_rows", "csum": "k_csum", "generate": "k_generate",
         "txbuild": "k_tx_build"}
 t = {}
+try:
+    t = json.load(open("profiles/traffic.json"))
+except (OSError, ValueError):
+    pass
 for w, k in kern.items():
-    if not os.path.exists(f"{P}/bench_{w}.json"):
+    if not os.path.exists(f"{P}/bench_{w}.json") or not os.path.exists(f"{P}/{w}_fetch/f_counter_collection.csv"):
         continue
-    shutil.copy(f"{P}/{w}_stats/s_kernel_stats.csv", f"{D}/{w}_kernel_stats.csv")
-    shutil.copy(f"{P}/bench_{w}.json", f"{D}/bench_{w}_1gpu.json")
+    put(f"{P}/{w}_stats/s_kernel_stats.csv", f"{D}/{w}_kernel_stats.csv")
+    put(f"{P}/bench_{w}.json", f"{D}/bench_{w}_1gpu.json")
     j = json.load(open(f"{P}/bench_{w}.json"))
     ab, n, alg = j["config"]["arena_bytes_rank0"], j["config"]["rank0_frames"], j["roofline"]["algorithmic_bytes_per_launch"]
     out = subprocess.check_output([sys.executable, "tools/pmc_traffic.py", f"{P}/{w}_fetch/f_counter_collection.csv",
@@ -28,8 +47,8 @@ for w, k in kern.items():
     r = json.loads(out)
     extra = "" if w == "hdr20" else " --rotate 1"
     t[w] = {"frames": n, "kernel": j["roofline"]["kernel"], "traffic_bytes": r["traffic_bytes"], "read_bytes": r["read_bytes"],
-            "write_bytes": r["write_bytes"],
-            "source": f"profiles/{rnd}/{w}_traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `python3 bench.py "
+            "write_bytes": r["write_bytes"], "kernels_sha256": j["roofline"]["kernels_sha256"],
+            "source": f"profiles/{tag}/{w}_traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `python3 bench.py "
                       f"--workload {w} --steps 3 --warmup 1{extra}`; KiB units, FETCH_SIZE doubled per the gfx950 calibration on k_stream_read)"}
     rows = list(csv.DictReader(open(f"{P}/{w}_stats/s_kernel_stats.csv")))
     ro = j["roofline"]
@@ -37,10 +56,13 @@ for w, k in kern.items():
           round(ro["achieved"]), "frac", round(ro["frac"], 3), "value", round(j["value"], 3), "traffic/alg", round(r["traffic_bytes"] / alg, 4),
           "parity", j.get("parity_check"))
 json.dump(t, open("profiles/traffic.json", "w"), indent=1)
-for src, dst in (("bench_trace.json", "bench_trace_2p30_1gpu.json"), ("bench_eth1514.json", "bench_eth1514_l2_1gpu.json"),
-                 ("size_sweep.jsonl", "size_sweep_verify_csum.jsonl"), ("tx_sweep.jsonl", "size_sweep_tx_build.jsonl")):
-    if os.path.exists(f"{P}/{src}"):
-        shutil.copy(f"{P}/{src}", f"{D}/{dst}")
-        if src.endswith(".json"):
-            j = json.load(open(f"{P}/{src}"))
-            print(src, round(j["value"], 3), j["unit"], round(j["roofline"]["achieved"]), "GB/s", "frac", round(j["roofline"]["frac"], 3))
+for src, dst in (("bench_fields.json", "bench_fields_1gpu.json"), ("bench_tximix.json", "bench_tximix_1gpu.json"),
+                 ("bench_eth1514.json", "bench_eth1514_l2_1gpu.json"), ("bench_udp1500_with_cpu.json", "bench_udp1500_with_cpu_baseline.json"),
+                 ("bench_udp1500_emulated_rank3of8.json", "bench_udp1500_emulated_rank3of8.json"),
+                 ("bench_trace_emulated_rank2of8_4chunks.json", "bench_trace_emulated_rank2of8_4chunks.json"),
+                 ("bench_trace_8chunks.json", "bench_trace_8chunks_1gpu.json"), ("host_path_pcie_inclusive.json", "host_path_pcie_inclusive.json"),
+                 ("size_sweep.jsonl", "size_sweep_verify_csum.jsonl"), ("tx_sweep.jsonl", "size_sweep_tx_build.jsonl"),
+                 ("batch_sweep.jsonl", "batch_size_sweep.jsonl")):
+    if put(f"{P}/{src}", f"{D}/{dst}") and src.startswith("bench_"):
+        j = json.load(open(f"{P}/{src}"))
+        print(src, round(j["value"], 3), j["unit"], round(j["roofline"]["achieved"]), "GB/s", "frac", round(j["roofline"]["frac"], 3))

@@ -1,13 +1,18 @@
 #!/bin/bash
-# Kernel-trace statistics and the two HBM-traffic counter passes for the bench workloads, as separate
-# rocprofv3 runs.  Run on the GPU box from the repo root; results land under gpurun_out/profile/.
-# usage: tools/profile_all.sh <workload>...
+# Everything the measurement section of DESIGN.md cites, produced in one go on the GPU box, under
+# gpurun_out/profile_<tag>/ (tools/collect_profiles.py <tag> then copies it to profiles/<tag>/):
+#   per workload: bench JSON under rocprofv3 --kernel-trace --stats, and the two HBM-traffic counter passes
+#   bench JSONs without a profiler for the remaining workloads, the emulated ranks of an 8-GPU job
+#   size sweeps of k_verify / k_csum and of k_tx_build, the batch-size sweep, the host-pointer rate
+# usage: tools/profile_all.sh <tag> [part]      part: pmc | bench | sweeps | all (default)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$R/gpurun_out/profile
+tag=${1:?tag}; part=${2:-all}
+OUT=$R/gpurun_out/profile_$tag
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-for w in "$@"; do
+if [ "$part" = pmc ] || [ "$part" = all ]; then
+for w in udp1500 imix odd hdr20 csum generate txbuild; do
   extra=""
   [ "$w" = hdr20 ] || extra="--rotate 1"
   timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${w}_stats" -o s -- python3 "$R/bench.py" --workload "$w" --cpu-seconds 0 > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err" || exit 1
@@ -15,3 +20,26 @@ for w in "$@"; do
   timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/${w}_write" -o w -- python3 "$R/bench.py" --workload "$w" --steps 3 --warmup 1 --cpu-seconds 0 $extra > /dev/null 2>&1 || exit 1
   echo "profiled $w"
 done
+fi
+if [ "$part" = bench ] || [ "$part" = all ]; then
+cd "$R"
+for w in fields tximix eth1514; do
+  timeout -k 10 200 python3 bench.py --workload $w --cpu-seconds 0 > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err" || exit 2
+  echo "bench $w"
+done
+timeout -k 10 300 python3 bench.py --workload udp1500 --cpu-seconds 10 > "$OUT/bench_udp1500_with_cpu.json" 2> "$OUT/bench_udp1500_with_cpu.err" || exit 2
+timeout -k 10 300 python3 bench.py --workload udp1500 --emulate-world 8 --emulate-rank 3 --cpu-seconds 0 > "$OUT/bench_udp1500_emulated_rank3of8.json" 2>> "$OUT/bench.err" || exit 2
+timeout -k 10 300 python3 bench.py --workload trace --emulate-world 8 --emulate-rank 2 --steps 4 --cpu-seconds 0 > "$OUT/bench_trace_emulated_rank2of8_4chunks.json" 2>> "$OUT/bench.err" || exit 2
+timeout -k 10 400 python3 bench.py --workload trace --steps 8 --total-frames $((1<<27)) --cpu-seconds 0 > "$OUT/bench_trace_8chunks.json" 2>> "$OUT/bench.err" || exit 2
+echo "bench extra done"
+timeout -k 10 300 python3 tools/host_path_bench.py > "$OUT/host_path_pcie_inclusive.json" 2>> "$OUT/bench.err" || exit 2
+fi
+if [ "$part" = sweeps ] || [ "$part" = all ]; then
+cd "$R"
+timeout -k 10 500 python3 tools/size_sweep.py 20 40 64 65 80 81 96 100 112 113 128 160 208 256 400 512 576 577 800 1024 1040 1499 1500 2048 4096 9000 65535 > "$OUT/size_sweep.jsonl" 2> "$OUT/size_sweep.err" || exit 3
+echo "size sweep done"
+timeout -k 10 500 python3 tools/tx_sweep.py > "$OUT/tx_sweep.jsonl" 2> "$OUT/tx_sweep.err" || exit 3
+echo "tx sweep done"
+timeout -k 10 500 python3 tools/batch_sweep.py > "$OUT/batch_sweep.jsonl" 2> "$OUT/batch_sweep.err" || exit 3
+echo "batch sweep done"
+fi

@@ -719,7 +719,7 @@ __global__ __launch_bounds__(kBlock, (TILE == 64 ? UNET_OCC64 : 6) * (256 / UNET
     u32 my_seed = 0;
     if (seeds && t.lane < t.cnt) my_seed = seeds[t.first + t.lane];
     u32 res = 0;
-    tile_run<TILE, false>(b, t, park, [&](u32 total, bool mine_now) {
+    tile_run<TILE, false>(b, t, park, [&](u32 total, bool mine_now) __attribute__((always_inline)) {
         // the seed is an already-folded partial sum in the big-endian domain (src/utils.rs:2)
         if (mine_now && t.my_ok) res = finish(total + bswap16(my_seed));
     });
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(kBlock, (TILE == 64 ? UNET_OCC64 : 6) * (256 / UNET
     Tile t;
     if (!t.init<TILE>(b)) return;
     u32 res = 0;  // V_NONE for records whose length/offset is out of range
-    tile_run<TILE, true>(b, t, park, [&](u32 total, bool mine_now) {
+    tile_run<TILE, true>(b, t, park, [&](u32 total, bool mine_now) __attribute__((always_inline)) {
         if (mine_now && t.my_ok) {
             LdsFetch f;
             f.w = reinterpret_cast<const u32*>(t.my_hdr);
@@ -826,20 +826,23 @@ __global__ __launch_bounds__(kBlock, (TILE == 64 ? UNET_OCC64 : 6) * (256 / UNET
     if (!t.init<TILE>(b)) return;
     u32 st = V_DROP_L3_TRUNCATED;  // also reported for out-of-range lengths/offsets
     u32 my_fields = 0;
-    tile_run<TILE, true>(b, t, park, [&](u32 total, bool mine_now) {
+    tile_run<TILE, true>(b, t, park, [&](u32 total, bool mine_now) __attribute__((always_inline)) {
     if (mine_now && t.my_ok && t.my_len >= 20u) {
+        // (locals, assigned to the captured results once at the end: writes through the captures from several
+        // branches end up as stores to stack memory)
+        u32 st_ = 0, fields_ = 0;
         const u32* w = reinterpret_cast<const u32*>(t.my_hdr);
         const u32 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
         const u32 proto = (w2 >> 8) & 0xffu;
         const u32 vhl = w0 & 0xffu;
         const u32 seglen = t.my_len - 20u;
-        if (!(proto == 1u || proto == 17u)) st = V_DROP_L3_PROTO;
-        else if ((vhl >> 4) != 4u) st = V_DROP_L3_VERSION;
-        else if ((vhl & 0xfu) < 5u) st = V_DROP_L3_IHL_SHORT;
-        else if ((vhl & 0xfu) > 5u) st = V_DROP_L3_IHL_LONG;
-        else if (seglen < 8u) st = proto == 17u ? V_DROP_UDP_SHORT : V_DROP_ICMP_TRUNCATED;
+        if (!(proto == 1u || proto == 17u)) st_ = V_DROP_L3_PROTO;
+        else if ((vhl >> 4) != 4u) st_ = V_DROP_L3_VERSION;
+        else if ((vhl & 0xfu) < 5u) st_ = V_DROP_L3_IHL_SHORT;
+        else if ((vhl & 0xfu) > 5u) st_ = V_DROP_L3_IHL_LONG;
+        else if (seglen < 8u) st_ = proto == 17u ? V_DROP_UDP_SHORT : V_DROP_ICMP_TRUNCATED;
         else {
-            st = 0;
+            st_ = 0;
             // IPv4 header field zeroed, then summed (src/protocols/ipv4.rs:374-389)
             const u32 hdr = halves(w0) + halves(w1) + (w2 & 0xffffu) + halves(w3) + halves(w4);
             const u32 prefix = hdr + (w2 >> 16);
@@ -856,7 +859,7 @@ __global__ __launch_bounds__(kBlock, (TILE == 64 ? UNET_OCC64 : 6) * (256 / UNET
                 w5 = (w5 & 0xffffu) | (bswap16(l4ck) << 16);  // message bytes 2..3 = packet bytes 22..23
             }
             const u32 ipck = finish(hdr);
-            my_fields = ipck | (l4ck << 16);
+            fields_ = ipck | (l4ck << 16);
             // Both fields live in the packet's first 32 bytes: store those two chunks whole instead of
             // two 2-byte pokes.  (Measured: the kernel without these stores runs at 6.9 TB/s, with them
             // at 4.7 TB/s -- one partial-line write per record into the stream being read costs a
@@ -867,6 +870,8 @@ __global__ __launch_bounds__(kBlock, (TILE == 64 ? UNET_OCC64 : 6) * (256 / UNET
                 rec[1] = u32x4{w4, w5, w6, w[7]};
             }
         }
+        st = st_;
+        my_fields = fields_;
     }
     });
     if (!IN_PLACE && t.lane < t.cnt) fields[t.first + t.lane] = my_fields;
