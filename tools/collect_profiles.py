@@ -62,7 +62,7 @@ for src, dst in (("bench_fields.json", "bench_fields_1gpu.json"), ("bench_tximix
                  ("bench_trace_emulated_rank2of8_4chunks.json", "bench_trace_emulated_rank2of8_4chunks.json"),
                  ("bench_trace_8chunks.json", "bench_trace_8chunks_1gpu.json"), ("host_path_pcie_inclusive.json", "host_path_pcie_inclusive.json"),
                  ("size_sweep.jsonl", "size_sweep_verify_csum.jsonl"), ("tx_sweep.jsonl", "size_sweep_tx_build.jsonl"),
-                 ("batch_sweep.jsonl", "batch_size_sweep.jsonl")):
+                 ("batch_sweep.jsonl", "batch_size_sweep.jsonl"), ("pmc_short_records.jsonl", "pmc_short_records.jsonl")):
     if put(f"{P}/{src}", f"{D}/{dst}") and src.startswith("bench_"):
         j = json.load(open(f"{P}/{src}"))
         print(src, round(j["value"], 3), j["unit"], round(j["roofline"]["achieved"]), "GB/s", "frac", round(j["roofline"]["frac"], 3))

@@ -43,3 +43,9 @@ echo "tx sweep done"
 timeout -k 10 500 python3 tools/batch_sweep.py > "$OUT/batch_sweep.jsonl" 2> "$OUT/batch_sweep.err" || exit 3
 echo "batch sweep done"
 fi
+if [ "$part" = sizes ] || [ "$part" = all ]; then
+cd "$R"
+bash tools/pmc_sizes.sh $tag 20 40 64 65 100 128 256 > "$OUT/pmc_sizes.log" 2>&1 || exit 4
+python3 tools/pmc_sizes.py "$R/gpurun_out/pmc_sizes_$tag" 5 20 40 64 65 100 128 256 > "$OUT/pmc_short_records.jsonl" 2>> "$OUT/pmc_sizes.log" || exit 4
+echo "pmc sizes done"
+fi
