@@ -452,10 +452,17 @@ class Offload:
         t = C.c_uint32(0)
         _check(self.lib.unet_verify_async(self.h, _np_ptr(arena), arena.nbytes, _np_ptr(off16), stride16, _np_ptr(lens), n,
                                           C.byref(ic), _np_ptr(out), C.byref(t)))
+        # the library writes into `out` during wait(): keep it alive until then even if the caller drops it
+        if not hasattr(self, "_inflight"):
+            self._inflight = {}
+        self._inflight[int(t.value)] = out
         return int(t.value), out
 
     def wait(self, ticket: int):
-        _check(self.lib.unet_wait(self.h, ticket))
+        try:
+            _check(self.lib.unet_wait(self.h, ticket))
+        finally:
+            getattr(self, "_inflight", {}).pop(int(ticket), None)
 
     def counters(self, reset: bool = False) -> np.ndarray:
         out = np.zeros(V_COUNT, dtype=np.uint64)

@@ -36,6 +36,21 @@ struct Batch {
 #ifndef UNET_SPAN_PATH
 #define UNET_SPAN_PATH 1      // tile_sums: tiles of short records staged in LDS as one coalesced byte range
 #endif
+#ifndef UNET_STREAM_PATH
+#define UNET_STREAM_PATH 1    // tile_run: 32-record tiles whose records lie back to back are read as one byte stream
+#endif
+#ifndef UNET_STREAM_TILE16
+#define UNET_STREAM_TILE16 0  // stream route for the 16-record tiles of long records too
+#endif
+#ifndef UNET_STREAM_MAX_CHUNKS
+#define UNET_STREAM_MAX_CHUNKS 0  // stream route only for tiles of at most this many chunks (0: any)
+#endif
+#ifndef UNET_STREAM_DEPTH
+#define UNET_STREAM_DEPTH 4   // stream route: register rows in rotation (one less is in flight)
+#endif
+#ifndef UNET_SPAN_ONLY64
+#define UNET_SPAN_ONLY64 0    // experiment: 32-record tiles of short records take the stream route instead of LDS staging
+#endif
 #ifndef UNET_TX_SMALL_PATH
 #define UNET_TX_SMALL_PATH 1  // k_tx_build: one lane per packet up to 48-byte payloads
 #endif
@@ -112,8 +127,11 @@ struct TileGeom {
     static constexpr u32 kPass = TILE < 32 ? (u32)TILE : 32u;   // records per pass; record j is parked at slot j % kPass
     static constexpr u32 kPasses = (u32)TILE / kPass;           // 1 or 2
     // chunks of the park area: kPass record areas, rounded up to whole 1 KiB rows for the span route
-    static constexpr u32 kPark = TILE >= 32 ? 256u : kPass * kLdsChunksPerRec;
-    static constexpr u32 kWaveLds = kPark + (2u * (u32)TILE + 3u) / 4u;  // + TILE u32 sums + TILE u32 list entries
+    static constexpr bool kStream = UNET_STREAM_PATH && (TILE == 32 || (UNET_STREAM_TILE16 && TILE == 16));  // the stream route
+    // (its bitmaps, 32 chunks, sit behind the record areas: in the unused end of the 256 chunks, or appended)
+    static constexpr u32 kPark = TILE >= 32 ? 256u : kPass * kLdsChunksPerRec + (kStream ? 32u : 0u);
+    static constexpr u32 kLists = (2u * (u32)TILE + 3u) / 4u;            // TILE u32 sums + TILE u32 list entries
+    static constexpr u32 kWaveLds = kPark + kLists;
     static_assert(kPark >= kPass * kLdsChunksPerRec, "park area holds a pass of records");
 };
 
@@ -301,6 +319,11 @@ __device__ __forceinline__ u32 from_lane(u32 v, u32 src_lane) {
     return (u32)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
 }
 
+// Lane i receives lane i+1's value; lane 63 receives `after` (DPP wave_shl:1, unwritten lanes keep `old`).
+__device__ __forceinline__ u32 from_next_lane(u32 v, u32 after) {
+    return (u32)__builtin_amdgcn_update_dpp((int)after, (int)v, 0x130, 0xf, 0xf, false);
+}
+
 // Mid-size records, 64/W at a time, W (8 or 16) neighbouring lanes per record -- a whole wave on one such
 // record would leave most lanes idle and keep little in flight.  Lane `sub` of a group loads chunks sub,
 // sub+W, sub+2W, sub+3W of its group's record (exactly four loads, clamped to the last chunk, default
@@ -471,6 +494,172 @@ __device__ __forceinline__ u32 span_sums(const SpanPlan& sp, Tile& t, u32x4* __r
         }
     }
     return some ? acc : 0u;
+}
+
+// ---- stream route.  A tile whose records lie back to back in the arena, in index order and without gaps -- any
+// packed batch -- is one byte range.  The wave reads that range in whole 1 KiB rows (lane L of row r holds chunk
+// 64 r + L of the range), streaming, three rows in flight, whatever the records' lengths: every 128-byte line is
+// requested by exactly one instruction, where the lane-group route asks for the two ends of a record's lines from
+// different instructions and so has to keep them cached.
+//   Which record a chunk belongs to comes from two bitmaps with one bit per chunk, built once per tile in LDS:
+// S marks the chunks a record starts on, C the cut last chunks (records whose length is not a multiple of 16).
+// A row's 64 bits of each are wave-uniform, so the masks "summed whole", "last chunk of its record in this row"
+// and the count of records begun in earlier rows are scalar arithmetic; the record number of a lane is that
+// count plus the S bits up to the lane.  Per row the lanes take an (unconditional) inclusive prefix sum P of
+// their chunk sums; the last lane e of each record's run adds P[e] to the record's total in LDS and takes it off
+// the next record's, which leaves every record with exactly the sum of its own chunks (mod 2^32, and the true
+// sums are below 2^31).  Header chunks and cut chunks are parked as in the general route.
+constexpr u32 kStreamRows = 32;  // rows per bitmap build (16 bytes per row): a longer range is worked through in segments of 32 KiB
+
+// Inclusive prefix sum over the 64 lanes.
+__device__ __forceinline__ u32 wave_prefix(u32 v) {
+    v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+__device__ __forceinline__ u64 uniform64(u32x4 w, bool second) {
+    const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(second ? w.z : w.x));
+    const u32 hi = (u32)__builtin_amdgcn_readfirstlane((int)(second ? w.w : w.y));
+    return (u64)hi << 32 | lo;
+}
+
+// Wave-uniform: does the tile take the stream route, and over which chunks [base, base + span) of the arena;
+// `lead` chunks at the front of the range (it starts on a 128-byte line) belong to no record of the tile.
+template <int TILE>
+__device__ __forceinline__ bool plan_stream(const Tile& t, u32 my_nch, u32* base, u32* span, u32* lead) {
+    static_assert(TileGeom<TILE>::kPark >= (u32)TILE * kLdsChunksPerRec + kStreamRows, "bitmaps behind the record areas");
+    const bool in = t.lane < t.cnt;
+    const u32 next_slot = from_next_lane(t.my_slot, 0xffffffffu);
+    const bool is_last = t.lane + 1u >= t.cnt;
+    // every record valid, non-empty (two records may not start on the same chunk) and followed at once by the next
+    const bool fits = !in || (t.my_ok && my_nch >= 1u && t.my_slot <= 0xffff0000u && (is_last || t.my_slot + my_nch == next_slot));
+    if (__ballot(fits) != ~0ull) return false;
+    const u32 lo = rdlane(t.my_slot, 0u);
+    const u32 end = rdlane(t.my_slot + my_nch, t.cnt - 1u);
+    *base = lo & ~7u;
+    *lead = lo & 7u;
+    *span = end - *base;
+    return UNET_STREAM_MAX_CHUNKS == 0 || *span <= (u32)UNET_STREAM_MAX_CHUNKS;
+}
+
+// One row.  `w` = {S, C} of this row; `carry` = records begun in earlier rows.
+template <int TILE, bool PARK_HDR>
+__device__ __forceinline__ void stream_row(const u32x4 v, const u32x4 w, u32 row, u32 span, u32 lead, const Tile& t, u32 my_rel,
+                                           u32x4* __restrict__ park, u32* __restrict__ sums, u32& carry) {
+    const u64 S = uniform64(w, false), C = uniform64(w, true);
+    const u32 left = span - row * kWave;  // chunks of the range from this row on
+    u64 valid = left >= kWave ? ~0ull : (1ull << left) - 1ull;
+    if (row == 0u) valid &= ~0ull << lead;
+    // record number: records begun before this row + S bits at or below the lane, less one
+    const u64 S1 = S >> 1;
+    const u32 c0 = carry + (u32)(S & 1ull) - 1u;
+    const u32 rid = __builtin_amdgcn_mbcnt_hi((u32)(S1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)S1, c0));
+    carry += (u32)__builtin_popcountll(S);
+    u32x4* area = park + rid * kLdsChunksPerRec;
+    // wave-uniform masks become per-lane conditions with no vector arithmetic
+    if (PARK_HDR) {
+        const u32 ci = row * kWave + t.lane - from_lane(my_rel, rid);
+        if (__builtin_amdgcn_inverse_ballot_w64(valid) && ci < kHdrChunks) area[ci] = v;
+    }
+    if (__builtin_amdgcn_inverse_ballot_w64(C & valid)) area[kHdrChunks] = v;
+    const u32 P = wave_prefix(sum_chunk(zero_unless(v, __builtin_amdgcn_inverse_ballot_w64(valid & ~C)), 0u));
+    // the last lane of every run: the lane before a record start, and the row's last chunk
+    const u64 before_start = S1 & valid;
+    const u64 row_end = 1ull << (min(left, kWave) - 1u);
+    if (__builtin_amdgcn_inverse_ballot_w64(before_start | row_end)) {
+        __hip_atomic_fetch_add(sums + rid, P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (__builtin_amdgcn_inverse_ballot_w64(before_start)) __hip_atomic_fetch_sub(sums + rid + 1u, P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+}
+
+// Exact sum of the lane's own record; t.my_hdr points at its parked chunks 0..5 afterwards.
+template <int TILE, bool PARK_HDR>
+__device__ __forceinline__ u32 stream_sums(const Batch& b, Tile& t, u32 base, u32 span, u32 lead, u32x4* __restrict__ park) {
+    typedef TileGeom<TILE> G;
+    static_assert(G::kPasses == 1u, "one park slot per record of the tile");
+    u32* sums = reinterpret_cast<u32*>(park + G::kPark);
+    u32x4* bm = park + (u32)TILE * kLdsChunksPerRec;  // row r: {S lo, S hi, C lo, C hi}
+    const bool in = t.lane < t.cnt;
+    const u32 my_rel = t.my_slot - base;
+    // D register rows in rotation, D - 1 loads in flight; the first ones go out before the bitmaps are built
+    constexpr u32 D = UNET_STREAM_DEPTH;
+    const u32 nrows = (span + kWave - 1u) / kWave, lastc = span - 1u;
+    const u32x4* p = reinterpret_cast<const u32x4*>(b.arena) + (u64)base;
+#define UNET_STREAM_LD(R) ld_stream(p + min((R) * kWave + t.lane, lastc))
+    u32x4 r[D];
+#pragma unroll
+    for (u32 k = 0; k + 1u < D; ++k) r[k] = UNET_STREAM_LD(k);
+    static_assert(kStreamRows % D == 0u, "a bitmap segment is a whole number of rotations");
+    if (t.lane < (u32)TILE) sums[t.lane] = 0u;
+    const u32 my_cut = (t.my_len & 15u) != 0u ? my_rel + (t.my_len >> 4) : 0xffffffffu;
+    static_assert(D % 2u == 0u, "the two bitmap-row registers alternate with the row's parity");
+    u32 carry = 0, row = 0;
+    u32 next_start = 0;     // where the next record begins (the range's end after the last one): wave-uniform
+    u32 hdr_end = 0;        // where the header chunks of the running record end: wave-uniform
+    u32 acc_run = 0;        // per lane: chunk sums of rows that lie wholly inside one record, not yet credited to it
+    bool pending = false;   // wave-uniform: acc_run holds something
+    u32x4 wv[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
+#pragma nounroll
+    while (true) {
+        if (row % kStreamRows == 0u) {
+            // S and C bits of the chunks [64 row, 64 row + 2048)
+            if (t.lane < kStreamRows) bm[t.lane] = u32x4{0, 0, 0, 0};
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            u32* bits = reinterpret_cast<u32*>(bm);
+            const u32 s_at = my_rel - row * kWave, c_at = my_cut - row * kWave;
+            if (in && s_at < kStreamRows * kWave)
+                __hip_atomic_fetch_or(bits + (s_at >> 6) * 4u + ((s_at >> 5) & 1u), 1u << (s_at & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (in && my_cut != 0xffffffffu && c_at < kStreamRows * kWave)
+                __hip_atomic_fetch_or(bits + (c_at >> 6) * 4u + 2u + ((c_at >> 5) & 1u), 1u << (c_at & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            wv[0] = bm[0];
+        }
+        bool done = false;
+#pragma unroll
+        for (u32 k = 0; k < D; ++k) {
+            if (!done) {
+                const u32 rr = row + k;
+                r[(k + D - 1u) % D] = UNET_STREAM_LD(rr + D - 1u);
+                // the next row's bits, ahead of time (stale at a segment's end: re-read above)
+                wv[(k + 1u) & 1u] = bm[(rr + 1u) % kStreamRows];
+                if (rr != 0u && next_start > (rr + 1u) * kWave && rr * kWave >= hdr_end) {
+                    // the whole row, and the chunk after it, lie inside the record that is already running, past its
+                    // header chunks: nothing to park, nothing cut, no boundary
+                    acc_run = sum_chunk(r[k], acc_run);
+                    pending = true;
+                } else {
+                    if (pending) {
+                        const u32 whole_rows = wave_sum(acc_run);
+                        if (t.lane == 0u) __hip_atomic_fetch_add(sums + carry - 1u, whole_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        acc_run = 0u;
+                        pending = false;
+                    }
+                    stream_row<TILE, PARK_HDR>(r[k], wv[k & 1u], rr, span, lead, t, my_rel, park, sums, carry);
+                    next_start = carry < t.cnt ? rdlane(my_rel, carry) : span;
+                    if (PARK_HDR && carry != 0u) hdr_end = rdlane(my_rel, carry - 1u) + kHdrChunks;
+                }
+                done = rr + 1u >= nrows;  // (the last row holds the range's end: never skipped above, so nothing is pending here)
+            }
+        }
+        if (done) break;
+        row += D;
+    }
+#undef UNET_STREAM_LD
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    u32x4* mine = park + (t.lane % G::kPass) * kLdsChunksPerRec;
+    t.my_hdr = mine;
+    t.hdr_dwords = kHdrChunks * 4u;
+    u32 total = in ? sums[t.lane] : 0u;
+    if (in && (t.my_len & 15u) != 0u) total = sum_chunk(LaneTail(t.my_len).apply(mine[kHdrChunks]), total);
+    return total;
 }
 
 // General route, one pass: exact sum of the lane's own record if it belongs to this pass (lanes pass*kPass ..
@@ -687,10 +876,18 @@ __device__ __forceinline__ u32 lane_loop_pass(const Batch& b, Tile& t, u32 pass,
 // buffers of the general route.
 template <int TILE, bool PARK_HDR, class Fin>
 __device__ __forceinline__ void tile_run(const Batch& b, Tile& t, u32x4* __restrict__ park, Fin&& fin) {
-    if (UNET_SPAN_PATH) {
+    if (UNET_SPAN_PATH && (TILE == 64 || !UNET_SPAN_ONLY64)) {
         const SpanPlan sp = plan_span<TILE>(b, t, t.my_ok ? (t.my_len + 15u) >> 4 : 0u);
         if (sp.on) {
             const u32 total = span_sums<TILE>(sp, t, park);
+            fin(total, t.lane < t.cnt);
+            return;
+        }
+    }
+    if constexpr (TileGeom<TILE>::kStream) {
+        u32 base, span, lead;
+        if (plan_stream<TILE>(t, t.my_ok ? (t.my_len + 15u) >> 4 : 0u, &base, &span, &lead)) {
+            const u32 total = stream_sums<TILE, PARK_HDR>(b, t, base, span, lead, park);
             fin(total, t.lane < t.cnt);
             return;
         }
@@ -895,11 +1092,6 @@ __device__ __forceinline__ u32x4 splice(u32x4 lo, u32x4 hi) {
     if (R == 4) return u32x4{lo.y, lo.z, lo.w, hi.x};
     return u32x4{(lo.y >> 16) | (lo.z << 16), (lo.z >> 16) | (lo.w << 16), (lo.w >> 16) | (hi.x << 16),
                  (hi.x >> 16) | (hi.y << 16)};
-}
-
-// Lane i receives lane i+1's value; lane 63 receives `after` (DPP wave_shl:1, unwritten lanes keep `old`).
-__device__ __forceinline__ u32 from_next_lane(u32 v, u32 after) {
-    return (u32)__builtin_amdgcn_update_dpp((int)after, (int)v, 0x130, 0xf, 0xf, false);
 }
 
 __device__ __forceinline__ void tx_store(u32x4 v, u32x4* p) {
