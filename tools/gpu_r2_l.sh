@@ -1,11 +1,12 @@
 #!/bin/bash
 mkdir -p gpurun_out
-for f in 2097152 8388608 33554432 67108864; do
-for w in imix; do
-timeout -k 10 300 python bench.py --workload $w --cpu-seconds 0 --steps 20 --frames $f > gpurun_out/r2_l_${w}_$f.json 2> gpurun_out/r2_l_${w}_$f.err || exit 6
+for v in default d2 d6 d8 nostream; do
+lib=$PWD/unet_amd/lib/variants/$v.so; [ $v = default ] && lib=$PWD/unet_amd/lib/libunet_offload.so
+for w in imix odd trace; do
+UNET_OFFLOAD_LIB=$lib timeout -k 10 200 python bench.py --workload $w --cpu-seconds 0 --steps 20 > gpurun_out/r2_l_${w}_$v.json 2> gpurun_out/r2_l_${w}_$v.err || exit 6
 python - <<PY
 import json
-d=json.load(open('gpurun_out/r2_l_${w}_$f.json')); print('$f $w', round(d['roofline']['achieved']), round(d['value'],3), d['ms_per_step'])
+d=json.load(open('gpurun_out/r2_l_${w}_$v.json')); print('$v $w', round(d['roofline']['achieved']), round(d['value'],3))
 PY
 done
 done
