@@ -50,6 +50,12 @@ for w, k in kern.items():
             "write_bytes": r["write_bytes"], "kernels_sha256": j["roofline"]["kernels_sha256"],
             "source": f"profiles/{tag}/{w}_traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `python3 bench.py "
                       f"--workload {w} --steps 3 --warmup 1{extra}`; KiB units, FETCH_SIZE doubled per the gfx950 calibration on k_stream_read)"}
+    # the bench line was printed before this pass existed: give it the traffic of the same session's counter passes
+    # (same kernel digest), and say so
+    if j["roofline"].get("traffic") is None:
+        j["roofline"]["traffic"] = r["traffic_bytes"]
+        j["roofline"]["traffic_source"] = t[w]["source"] + "; joined to this line by tools/collect_profiles.py, same run of tools/profile_all.sh, same kernel digest"
+        json.dump(j, open(f"{D}/bench_{w}_1gpu.json", "w"))
     rows = list(csv.DictReader(open(f"{P}/{w}_stats/s_kernel_stats.csv")))
     ro = j["roofline"]
     print(w, rows[0]["Name"][:36], rows[0]["Calls"], round(float(rows[0]["AverageNs"]) / 1e3, 1), "us | bench ms", round(ro["kernel_ms"], 4), "GB/s",
