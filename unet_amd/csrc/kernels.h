@@ -23,6 +23,7 @@ struct Batch {
     u32 stride16;
     const u32* len;
     u32 n;
+    u32 tile_n = 0;  // records per wave if fewer than the kernel's TILE (0: TILE)
 };
 
 // Build-time switches for A/B measurements (each path can be compiled out; the wave-cooperative path then
@@ -158,9 +159,10 @@ struct Tile {
     __device__ __forceinline__ bool init(const Batch& b) {
         lane = threadIdx.x & 63u;
         const u32 wave = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-        first = wave * (u32)TILE;
+        const u32 per = b.tile_n != 0u && b.tile_n < (u32)TILE ? b.tile_n : (u32)TILE;
+        first = wave * per;
         if (first >= b.n) return false;
-        cnt = min((u32)TILE, b.n - first);
+        cnt = min(per, b.n - first);
         my_len = 0;
         my_slot = 0;
         my_ok = false;

@@ -277,8 +277,16 @@ constexpr u64 kShortMax = 64;
 inline int tile_for(u64 mean_len, bool max_known, u64 max_len) {
     if (mean_len > 1024) return 16;  // (records of exactly 1 KiB are still read faster as a stream, by 32-record tiles)
     const bool all_short = max_known ? max_len <= kShortMax : mean_len <= kShortMax;
-    return all_short ? 64 : 32;
+    if (all_short) return 64;
+    // Records of 65..96 bytes, the longest known: the same kernel, with as many records per wave as are sure to
+    // fit its 256-chunk staging area -- a multiple of eight, so that tiles of full-length records begin on
+    // 128-byte lines (48 of five chunks, 40 of six).  Those tiles are latency-bound and everything a wave reads
+    // is in flight at once: with 32 such records a wave would keep only 2.5-3 KiB of its 4 KiB on the way.
+    if (max_known && max_len > kShortMax && max_len <= 96) return (int)((256u / (u32)((max_len + 15u) / 16u)) & ~7u);
+    return 32;
 }
+// tile_for's answer -> the kernel instantiation that runs it (16, 32 or 64 records per wave at most)
+inline int kernel_tile(int tile) { return tile <= 16 ? 16 : (tile <= 32 ? 32 : 64); }
 // The device-pointer entry points cannot see the lengths: the mean record size is the caller's hint if one was
 // given (unet_hint_mean_len), else the fixed stride (which also bounds the length), else arena_bytes / n (right
 // for packed arenas).  The host-pointer entry points pass the true mean and maximum.
@@ -330,11 +338,14 @@ int upload_batch(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const 
     return UNET_OK;
 }
 
-int launch_verify(hipStream_t s, const Batch& b, const unet_iface* iface, int tile, u32* d_out) {
+int launch_verify(hipStream_t s, const Batch& b_in, const unet_iface* iface, int records_per_wave, u32* d_out) {
     const IfaceDev ifc = to_dev(iface);
+    Batch b = b_in;
+    b.tile_n = (u32)records_per_wave;
     const u32 n = b.n;
+    const int tile = kernel_tile(records_per_wave);
 #define UNET_LAUNCH_VERIFY(M, T) \
-    hipLaunchKernelGGL((k_verify<M, T>), dim3(tiles_grid(n, T)), dim3(kBlock), 0, s, b, ifc, d_out)
+    hipLaunchKernelGGL((k_verify<M, T>), dim3(tiles_grid(n, (u32)records_per_wave)), dim3(kBlock), 0, s, b, ifc, d_out)
     if (iface->mode == UNET_MODE_L2) {
         if (tile == 16) UNET_LAUNCH_VERIFY(MODE_L2, 16);
         else if (tile == 32) UNET_LAUNCH_VERIFY(MODE_L2, 32);
@@ -542,10 +553,12 @@ int unet_csum_batch_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uin
     HIP_TRY(hipSetDevice(ctx->device));
     Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
     if (arena_too_small(arena_bytes)) return fail(UNET_E_INVAL, "arena must hold at least 16 bytes");
-    switch (pick_tile(ctx, arena_bytes, stride16, n)) {
-        case 16: hipLaunchKernelGGL(k_csum<16>, dim3(tiles_grid(n, 16)), dim3(kBlock), 0, pick(ctx, stream), b, d_seeds, d_out); break;
-        case 32: hipLaunchKernelGGL(k_csum<32>, dim3(tiles_grid(n, 32)), dim3(kBlock), 0, pick(ctx, stream), b, d_seeds, d_out); break;
-        default: hipLaunchKernelGGL(k_csum<64>, dim3(tiles_grid(n, 64)), dim3(kBlock), 0, pick(ctx, stream), b, d_seeds, d_out); break;
+    b.tile_n = (u32)pick_tile(ctx, arena_bytes, stride16, n);
+    const dim3 grid(tiles_grid(n, b.tile_n));
+    switch (kernel_tile((int)b.tile_n)) {
+        case 16: hipLaunchKernelGGL(k_csum<16>, grid, dim3(kBlock), 0, pick(ctx, stream), b, d_seeds, d_out); break;
+        case 32: hipLaunchKernelGGL(k_csum<32>, grid, dim3(kBlock), 0, pick(ctx, stream), b, d_seeds, d_out); break;
+        default: hipLaunchKernelGGL(k_csum<64>, grid, dim3(kBlock), 0, pick(ctx, stream), b, d_seeds, d_out); break;
     }
     HIP_TRY(hipGetLastError());
     return UNET_OK;
@@ -819,10 +832,12 @@ int unet_generate_dev(unet_ctx* ctx, void* stream, uint8_t* d_arena, uint64_t ar
     HIP_TRY(hipSetDevice(ctx->device));
     Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
     if (arena_too_small(arena_bytes)) return fail(UNET_E_INVAL, "arena must hold at least 16 bytes");
-    switch (pick_tile(ctx, arena_bytes, stride16, n)) {
-        case 16: hipLaunchKernelGGL((k_generate<16, true>), dim3(tiles_grid(n, 16)), dim3(kBlock), 0, pick(ctx, stream), b, d_arena, (u32*)nullptr, d_status); break;
-        case 32: hipLaunchKernelGGL((k_generate<32, true>), dim3(tiles_grid(n, 32)), dim3(kBlock), 0, pick(ctx, stream), b, d_arena, (u32*)nullptr, d_status); break;
-        default: hipLaunchKernelGGL((k_generate<64, true>), dim3(tiles_grid(n, 64)), dim3(kBlock), 0, pick(ctx, stream), b, d_arena, (u32*)nullptr, d_status); break;
+    b.tile_n = (u32)pick_tile(ctx, arena_bytes, stride16, n);
+    const dim3 grid(tiles_grid(n, b.tile_n));
+    switch (kernel_tile((int)b.tile_n)) {
+        case 16: hipLaunchKernelGGL((k_generate<16, true>), grid, dim3(kBlock), 0, pick(ctx, stream), b, d_arena, (u32*)nullptr, d_status); break;
+        case 32: hipLaunchKernelGGL((k_generate<32, true>), grid, dim3(kBlock), 0, pick(ctx, stream), b, d_arena, (u32*)nullptr, d_status); break;
+        default: hipLaunchKernelGGL((k_generate<64, true>), grid, dim3(kBlock), 0, pick(ctx, stream), b, d_arena, (u32*)nullptr, d_status); break;
     }
     HIP_TRY(hipGetLastError());
     return UNET_OK;
@@ -838,10 +853,12 @@ int unet_checksum_fields_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena
     HIP_TRY(hipSetDevice(ctx->device));
     Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
     if (arena_too_small(arena_bytes)) return fail(UNET_E_INVAL, "arena must hold at least 16 bytes");
-    switch (pick_tile(ctx, arena_bytes, stride16, n)) {
-        case 16: hipLaunchKernelGGL((k_generate<16, false>), dim3(tiles_grid(n, 16)), dim3(kBlock), 0, pick(ctx, stream), b, (uint8_t*)nullptr, (u32*)d_fields, d_status); break;
-        case 32: hipLaunchKernelGGL((k_generate<32, false>), dim3(tiles_grid(n, 32)), dim3(kBlock), 0, pick(ctx, stream), b, (uint8_t*)nullptr, (u32*)d_fields, d_status); break;
-        default: hipLaunchKernelGGL((k_generate<64, false>), dim3(tiles_grid(n, 64)), dim3(kBlock), 0, pick(ctx, stream), b, (uint8_t*)nullptr, (u32*)d_fields, d_status); break;
+    b.tile_n = (u32)pick_tile(ctx, arena_bytes, stride16, n);
+    const dim3 grid(tiles_grid(n, b.tile_n));
+    switch (kernel_tile((int)b.tile_n)) {
+        case 16: hipLaunchKernelGGL((k_generate<16, false>), grid, dim3(kBlock), 0, pick(ctx, stream), b, (uint8_t*)nullptr, (u32*)d_fields, d_status); break;
+        case 32: hipLaunchKernelGGL((k_generate<32, false>), grid, dim3(kBlock), 0, pick(ctx, stream), b, (uint8_t*)nullptr, (u32*)d_fields, d_status); break;
+        default: hipLaunchKernelGGL((k_generate<64, false>), grid, dim3(kBlock), 0, pick(ctx, stream), b, (uint8_t*)nullptr, (u32*)d_fields, d_status); break;
     }
     HIP_TRY(hipGetLastError());
     return UNET_OK;
@@ -908,6 +925,7 @@ int unet_tx_build_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload_aren
     hipLaunchKernelGGL((k_tx_build<M, T>), dim3(tiles_grid(n, T)), dim3(kBlock), 0, pick(ctx, stream), b, (const TxDesc*)d_desc, ifc, \
                        d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status)
     int tile = pick_tile(ctx, payload_arena_bytes, payload_stride16, n);
+    if (tile > 32 && tile < 64) tile = 32;  // (the in-between sizes exist for the receive-side kernels only)
     if (ctx->tx_tile_override) tile = ctx->tx_tile_override;
     if (iface->mode == UNET_MODE_L2) {
         if (tile == 8) UNET_TX_LAUNCH(MODE_L2, 8);
