@@ -633,12 +633,12 @@ int unet_ipv4_validate_dev(unet_ctx* ctx, void* stream, const uint8_t* d_hdrs, u
     HIP_TRY(hipSetDevice(ctx->device));
     if (((uintptr_t)d_out & 15u) != 0) return fail(UNET_E_INVAL, "result buffer must be 16-byte aligned");
     const u32 ext = iface->ext_tcp ? 1u : 0u;
-    // whole workgroups of 1024 headers take the row kernel; the remainder (< 1024) the per-lane kernel
-    const u32 per_block = (kBlock / kWave) * kHdrPerWave;
+    // whole workgroups (256 headers per wave) take the row kernel; the remainder the per-lane kernel
+    const u32 per_block = (kHdrBlock / kWave) * kHdrPerWave;
     const u32 full_blocks = ctx->hdr_plain ? 0u : n / per_block;
     const u32 done = full_blocks * per_block;
     if (full_blocks)
-        hipLaunchKernelGGL(k_ipv4_validate_rows, dim3(full_blocks), dim3(kBlock), 0, pick(ctx, stream), (const u32x4*)d_hdrs, ext,
+        hipLaunchKernelGGL(k_ipv4_validate_rows, dim3(full_blocks), dim3(kHdrBlock), 0, pick(ctx, stream), (const u32x4*)d_hdrs, ext,
                            (u32x4*)d_out);
     if (n > done) {
         const u32 rest = n - done, per = kBlock * kHdrPerGroup;
