@@ -1,0 +1,120 @@
+"""Randomised parity soak: batches with random length mixes, layouts, modes and contents through unet_verify,
+unet_csum_batch and unet_generate, every result against the CPU oracle.  Not collected by pytest (it runs for as
+long as it is told to); tests/test_fuzz_short.py runs a few rounds of it.
+
+usage: python tests/fuzz_parity.py [seconds] [first seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import unet_amd  # noqa: E402
+from oracle import oracle_ffi as O  # noqa: E402
+
+LENGTH_CLASSES = [
+    lambda r, n: r.integers(0, 65, size=n),
+    lambda r, n: r.integers(20, 129, size=n),
+    lambda r, n: r.integers(65, 113, size=n),
+    lambda r, n: r.integers(1, 1025, size=n),
+    lambda r, n: r.integers(900, 1100, size=n),
+    lambda r, n: r.integers(1, 3000, size=n),
+    lambda r, n: r.choice([64, 576, 1500, 4096, 9000], p=[.56, .32, .08, .02, .02], size=n),
+    lambda r, n: r.choice([65, 577, 1499, 4097, 8999], p=[.56, .32, .08, .02, .02], size=n),
+    lambda r, n: np.where(r.random(n) < 0.01, 65535, r.integers(40, 400, size=n)),
+    lambda r, n: np.full(n, int(r.integers(1, 2100))),
+    lambda r, n: np.full(n, int(r.choice([64, 80, 96, 112, 128, 256, 512, 1024, 1040, 1504]))),
+]
+
+
+def make_frames(rng, n, ifc):
+    """Half valid traffic from the synthetic generator (cut or padded to the drawn length now and then), half noise."""
+    lens = np.asarray(LENGTH_CLASSES[int(rng.integers(len(LENGTH_CLASSES)))](rng, n), dtype=np.int64)
+    kind = unet_amd.SYNTH_ODD if rng.random() < 0.5 else unet_amd.SYNTH_IMIX
+    a, o, l = unet_amd.synth_host(kind, int(rng.integers(1, 2**31)), int(rng.integers(0, 2**20)), n, ifc)
+    frames = []
+    for i in range(n):
+        if rng.random() < 0.5:
+            f = a[int(o[i]) * 16:int(o[i]) * 16 + int(l[i])].tobytes()
+            if rng.random() < 0.2:
+                f = f[:int(lens[i])]
+        else:
+            f = rng.integers(0, 256, size=int(lens[i]), dtype=np.uint8).tobytes()
+        frames.append(f)
+    return frames
+
+
+def layout(rng, frames):
+    lens = np.array([len(f) for f in frames], dtype=np.uint32)
+    n = len(frames)
+    slots = (lens.astype(np.int64) + 15) // 16
+    how = int(rng.integers(6))
+    stride16 = 0
+    packed = np.concatenate([[0], np.cumsum(slots)[:-1]])
+    if how == 0:
+        off = packed
+    elif how == 1:
+        off = packed + int(rng.integers(1, 9))  # the first tile does not start on a 128-byte line
+    elif how == 2:
+        stride16 = int(slots.max()) + int(rng.integers(0, 2))
+        off = np.arange(n, dtype=np.int64) * stride16
+    elif how == 3:
+        off = packed + np.cumsum(rng.random(n) < 0.02)  # a gap now and then
+    elif how == 4:
+        perm = rng.permutation(n)
+        off = np.zeros(n, dtype=np.int64)
+        at = 0
+        for k in perm:
+            off[k] = at
+            at += int(slots[k])
+    else:
+        off = (int(packed[-1] + slots[-1]) - packed - slots)  # descending
+    size = int((off + slots).max()) * 16
+    arena = rng.integers(0, 256, size=max(size, 16), dtype=np.uint8)
+    for f, o in zip(frames, off):
+        arena[int(o) * 16:int(o) * 16 + len(f)] = np.frombuffer(f, dtype=np.uint8)
+    return arena, (None if stride16 else off.astype(np.uint32)), stride16, lens, how
+
+
+def one_round(ctx, seed):
+    rng = np.random.default_rng(seed)
+    mode = unet_amd.MODE_L2 if rng.random() < 0.3 else unet_amd.MODE_L3
+    ifc = unet_amd.Iface("192.0.2.2", "255.255.255.0", mac=bytes.fromhex("02aabbccddee"), mode=mode, ext_tcp=bool(rng.random() < 0.7))
+    n = int(rng.choice([1, 31, 32, 33, 63, 64, 65, 500, 2000, 5000]))
+    frames = make_frames(rng, n, ifc)
+    arena, off16, stride16, lens, how = layout(rng, frames)
+    tag = (seed, n, mode, how, int(lens.max()), round(float(lens.mean()), 1))
+    got = ctx.verify(arena, off16, lens, ifc, stride16=stride16)
+    exp = O.recv_batch(arena, off16, lens, ifc, stride16=stride16)
+    bad = np.nonzero(got != exp)[0]
+    assert bad.size == 0, ("verify", tag, bad[:5], got[bad[:5]], exp[bad[:5]], lens[bad[:5]])
+    seeds = rng.integers(0, 65536, size=n).astype(np.uint16)
+    g = ctx.csum_batch(arena, off16, lens, seeds, stride16=stride16)
+    e = O.csum_batch(arena, off16, lens, seeds, stride16=stride16)
+    assert (g == e).all(), ("csum", tag, np.nonzero(g != e)[0][:5])
+    if mode == unet_amd.MODE_L3:
+        ga, gs = ctx.generate(arena, off16, lens, stride16=stride16)
+        ea, es = O.generate_batch(arena, off16, lens, stride16=stride16)
+        assert (gs == es).all(), ("generate status", tag)
+        assert (ga == ea).all(), ("generate bytes", tag)
+    return tag
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0 = last = time.time()
+    rounds = 0
+    with unet_amd.Offload(0) as ctx:
+        while time.time() - t0 < seconds:
+            one_round(ctx, seed + rounds)
+            rounds += 1
+            if time.time() - last > 30:
+                last = time.time()
+                print(f"{rounds} rounds, {time.time() - t0:.0f} s", flush=True)
+    print(f"ok: {rounds} rounds from seed {seed}, every result equal to the oracle's")
+
+
+if __name__ == "__main__":
+    main()
