@@ -1,5 +1,5 @@
 """Randomised parity soak: batches with random length mixes, layouts, modes and contents through unet_verify,
-unet_csum_batch and unet_generate, every result against the CPU oracle.  Not collected by pytest (it runs for as
+unet_csum_batch, unet_generate and unet_tx_build, every result against the CPU oracle.  Not collected by pytest (it runs for as
 long as it is told to); tests/test_fuzz_short.py runs a few rounds of it.
 
 usage: python tests/fuzz_parity.py [seconds] [first seed]"""
@@ -101,6 +101,37 @@ def one_round(ctx, seed):
     return tag
 
 
+def tx_round(ctx, seed):
+    """unet_tx_build on payloads of a random length mix and layout, every packet byte against the oracle."""
+    from unet_amd._ffi import TX_DESC_DTYPE, tx_out_layout
+    rng = np.random.default_rng(seed)
+    mode = unet_amd.MODE_L2 if rng.random() < 0.4 else unet_amd.MODE_L3
+    ifc = unet_amd.Iface("192.0.2.2", "255.255.255.0", mac=bytes.fromhex("02aabbccddee"), mode=mode)
+    n = int(rng.choice([1, 15, 16, 17, 33, 64, 65, 300, 1500]))
+    lens = np.asarray(LENGTH_CLASSES[int(rng.integers(len(LENGTH_CLASSES)))](rng, n), dtype=np.int64)
+    frames = [rng.integers(0, 256, size=int(l), dtype=np.uint8).tobytes() for l in lens]
+    arena, off16, stride16, plen, how = layout(rng, frames)
+    desc = np.zeros(n, dtype=TX_DESC_DTYPE)
+    desc["src"] = np.where(rng.random(n) < 0.2, 0, ifc.unicast)
+    desc["dst"] = rng.integers(0, 2**32, size=n, dtype=np.uint64).astype(np.uint32)
+    desc["l4a"] = rng.integers(0, 65536, size=n)
+    desc["l4b"] = rng.integers(0, 65536, size=n)
+    desc["values"] = rng.integers(0, 2**32, size=n, dtype=np.uint64).astype(np.uint32)
+    desc["ip_id"] = rng.integers(0, 65536, size=n)
+    desc["proto"] = np.where(rng.random(n) < 0.3, 1, np.where(rng.random(n) < 0.02, 99, 17))
+    desc["dst_mac"] = rng.integers(0, 256, size=(n, 6), dtype=np.uint8)
+    tag = (seed, n, mode, how, int(plen.max()), round(float(plen.mean()), 1))
+    got, got_off, got_len, got_status = ctx.tx_build(arena, off16, plen, desc, ifc, payload_stride16=stride16)
+    ooff, obytes = tx_out_layout(plen, mode)
+    exp, exp_len, exp_status = O.tx_build_batch(arena, off16, plen, desc, ifc, ooff, obytes, pay_stride16=stride16)
+    assert (got_off == ooff).all() and got.nbytes == obytes, ("tx layout", tag)
+    assert (got_status == exp_status).all() and (got_len == exp_len).all(), ("tx status", tag)
+    for o, l in zip(ooff, exp_len):
+        a, b = int(o) * 16, int(o) * 16 + int(l)
+        assert (got[a:b] == exp[a:b]).all(), ("tx bytes", tag, int(o), int(l))
+    return tag
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -109,6 +140,7 @@ def main():
     with unet_amd.Offload(0) as ctx:
         while time.time() - t0 < seconds:
             one_round(ctx, seed + rounds)
+            tx_round(ctx, seed + rounds)
             rounds += 1
             if time.time() - last > 30:
                 last = time.time()

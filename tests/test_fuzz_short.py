@@ -1,9 +1,9 @@
 """A few rounds of the randomised parity soak (tests/fuzz_parity.py): random length mixes, layouts and modes through
-unet_verify, unet_csum_batch and unet_generate, against the CPU oracle."""
+unet_verify, unet_csum_batch, unet_generate and unet_tx_build, against the CPU oracle."""
 import pytest
 
 import unet_amd
-from fuzz_parity import one_round
+from fuzz_parity import one_round, tx_round
 
 pytestmark = pytest.mark.gpu
 
@@ -11,3 +11,4 @@ pytestmark = pytest.mark.gpu
 def test_fuzz_rounds(offload):
     for seed in range(1000, 1040):
         one_round(offload, seed)
+        tx_round(offload, seed)
