@@ -4,6 +4,7 @@
 //!   (src/utils.rs:1) and can replace it at its seven call sites;
 //! * [`Offload::recv_batch`] decides a whole drained protocol queue at once: what the loop of
 //!   `NetProtocol::recv` (src/protocols.rs:83-97) gets from `ipv4::recv` packet by packet;
+//! * [`Offload::send_batch`] builds the packets of a batch of `udp::send` / `icmp::send` requests;
 //! * [`Pipeline`] keeps two batches in flight from the stack's single main thread.
 //!
 //! NOT compiled where it was written (no rustc in that build image): treat it as reviewed source, not as a
@@ -135,6 +136,15 @@ impl Arena {
         Ok(())
     }
 
+    /// Record `i` as the caller pushed it (or as `send_batch` built it).
+    pub fn record(&self, i: usize) -> &[u8] {
+        let start = self.off16[i] as usize * 16;
+        // SAFETY: u128 has no padding and any bit pattern is a valid u8; the range lies inside the vector because
+        // push / unet_tx_build place every record, with its pad to 16 bytes, inside it.
+        let all = unsafe { std::slice::from_raw_parts(self.chunks.as_ptr() as *const u8, self.chunks.len() * 16) };
+        &all[start..start + self.len[i] as usize]
+    }
+
     fn bytes(&self) -> (*const u8, u64) {
         (self.chunks.as_ptr() as *const u8, (self.chunks.len() * 16) as u64)
     }
@@ -254,6 +264,43 @@ impl Offload {
             "unet_generate",
         )?;
         Ok(status)
+    }
+
+    /// Whole packets (L3 mode) or Ethernet frames (L2 mode) from payloads and descriptors: what `udp::send` /
+    /// `icmp::send` -> `ipv4::send` -> `tap::send` build one at a time (src/transport/udp.rs:168-216,
+    /// src/transport/icmp.rs:66-95, src/protocols/ipv4.rs:300-391, src/driver/tap.rs:132-166).  The decisions those
+    /// functions take on the host stay with the caller and arrive in the descriptor: route and source-address
+    /// checks, the identification counter, the resolved destination MAC.  Returns the packets as an arena (record
+    /// i is packet i; length 0 where the status is not 0) and one `UNET_TX_*` status per packet.
+    pub fn send_batch(&mut self, payloads: &Arena, desc: &[TxDesc], iface: &Iface) -> Result<(Arena, Vec<u8>)> {
+        let n = payloads.records();
+        ensure!(desc.len() == n, "{} descriptors for {} payloads", desc.len(), n);
+        let mut out = Arena::new();
+        let mut status = vec![0u8; n];
+        if n == 0 {
+            return Ok((out, status));
+        }
+        let mut out_bytes = 0u64;
+        out.off16 = vec![0u32; n];
+        out.len = vec![0u32; n];
+        // SAFETY: the tables hold n entries.
+        check(
+            unsafe { sys::unet_tx_layout(payloads.len.as_ptr(), n as u32, iface.mode as i32, out.off16.as_mut_ptr(), &mut out_bytes) },
+            "unet_tx_layout",
+        )?;
+        out.chunks = vec![0u128; (out_bytes / 16) as usize];
+        let (p, bytes) = payloads.bytes();
+        // SAFETY: the output arena has the size unet_tx_layout asked for; every table holds n entries.
+        check(
+            unsafe {
+                sys::unet_tx_build(
+                    self.ctx, p, bytes, payloads.off16.as_ptr(), 0, payloads.len.as_ptr(), desc.as_ptr(), n as u32, iface,
+                    out.chunks.as_mut_ptr() as *mut u8, out_bytes, out.off16.as_mut_ptr(), out.len.as_mut_ptr(), status.as_mut_ptr(),
+                )
+            },
+            "unet_tx_build",
+        )?;
+        Ok((out, status))
     }
 
     /// Per-verdict counts of everything this context has judged through host-pointer calls.
