@@ -2,7 +2,7 @@
 """Cost of one call as a function of batch size: the caller this offload replaces (the drain loop of
 src/protocols.rs:83-97) hands over a few to a few thousand frames at a time, not millions.
 
-For n in {1, 16, 256, 4096, 65536, 1048576} records of 64 / 1500 / 9000 bytes: microseconds per call of
+For n in {1, 16, 64, 256, 1024, 4096, 65536, 1048576} records of 64 / 1500 / 9000 bytes: microseconds per call of
   unet_verify         host pointers (staging, H2D, kernel, D2H, wait)
   unet_verify_static  the same through the static device scratch (n <= 65536, arena <= 8 MiB)
   unet_verify_async   two batches in flight, per-call cost in steady state
@@ -61,7 +61,7 @@ def main():
     st = torch.cuda.Stream()
     torch.cuda.set_stream(st)
     sizes = [64, 1500, 9000]
-    counts = [1, 16, 256, 4096, 65536, 1 << 20]
+    counts = [1, 16, 64, 256, 1024, 4096, 65536, 1 << 20]
     for size in sizes:
         cross = {}
         for n in counts:

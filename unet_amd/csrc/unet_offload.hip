@@ -175,6 +175,9 @@ struct unet_ctx {
     hipStream_t s_comp = nullptr;  // kernels (and D2H of results)
     hipStream_t s_copy = nullptr;  // H2D staging
     void* pinned[2] = {nullptr, nullptr};
+    void* pinned_dev[2] = {nullptr, nullptr};  // the same buffers as the device addresses kernels may use
+    uint64_t host_counts[UNET_V_COUNT] = {};   // verdicts of the batches judged in place (added to d_counts by unet_counters)
+    u64 zero_copy_bytes = 4u << 20;            // staging images up to this size may be read in place (UNET_ZERO_COPY_BYTES)
     hipEvent_t pinned_free[2] = {nullptr, nullptr};
     hipEvent_t copied = nullptr;
     DevBuf d_arena, d_off, d_len, d_out, d_aux, d_tx, d_tx_tab, d_tcp;
@@ -273,6 +276,7 @@ inline bool arena_too_small(u64 arena_bytes) { return arena_bytes < 16; }
 // it fits 4 KiB and reads any other tile with plain per-lane loops (correct for every length, slow for long
 // ones).  So it is chosen when the longest record is known to be that short, or -- lengths unseen -- when the
 // mean is so low that hardly any record can be longer.
+constexpr u64 kInPlaceOneWave = 64u << 10;  // what one wave may be left to read across the host link (see unet_verify)
 constexpr u64 kShortMax = 64;
 inline int tile_for(u64 mean_len, bool max_known, u64 max_len) {
     if (mean_len > 1024) return 16;  // (records of exactly 1 KiB are still read faster as a stream, by 32-record tiles)
@@ -453,6 +457,7 @@ int unet_open(int device_id, unet_ctx** out_ctx) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; i++) {
         e = hipHostMalloc(&c->pinned[i], kStageBytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(&c->pinned_dev[i], c->pinned[i], 0);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->pinned_free[i], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->copied, hipEventDisableTiming);
@@ -491,6 +496,7 @@ int unet_open(int device_id, unet_ctx** out_ctx) {
         c->tile_override = v <= 16 ? 16 : (v <= 32 ? 32 : 64);
     }
     c->hdr_plain = getenv("UNET_HDR_PLAIN") != nullptr;
+    if (const char* z = getenv("UNET_ZERO_COPY_BYTES")) c->zero_copy_bytes = strtoull(z, nullptr, 10);
     if (const char* t = getenv("UNET_TX_TILE")) {
         const int v = atoi(t);
         c->tx_tile_override = v <= 4 ? 4 : (v <= 8 ? 8 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)));
@@ -608,6 +614,17 @@ int unet_csum(unet_ctx* c, const uint8_t* data, size_t len, uint16_t seed, uint1
     memcpy(pin, &l32, 4);
     memcpy(pin + 4, &seed, 2);
     if (len) memcpy(pin + 16, data, len);
+    if (total <= kInPlaceOneWave && total <= c->zero_copy_bytes) {
+        // a buffer one wave reads in a few rows: the kernel takes it out of the pinned buffer itself (see unet_verify)
+        const uint8_t* hd = (const uint8_t*)c->pinned_dev[0];
+        LenScope hint(c, (u32)len, (u32)len);
+        if ((rc = unet_csum_batch_dev(c, nullptr, hd + 16, total - 16, nullptr, 1, (const u32*)hd, (const uint16_t*)(hd + 4), 1,
+                                      (uint16_t*)c->pinned_dev[1])))
+            return rc;
+        HIP_TRY(hipStreamSynchronize(c->s_comp));
+        memcpy(out, c->pinned[1], 2);
+        return UNET_OK;
+    }
     uint8_t* dev = (uint8_t*)c->d_arena.p;
     HIP_TRY(hipMemcpyAsync(dev, pin, total, hipMemcpyHostToDevice, c->s_comp));
     uint16_t* d_out = (uint16_t*)(dev + ((total + 255) & ~(size_t)255));
@@ -700,6 +717,26 @@ int unet_verify(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const u
         HIP_TRY(hipEventSynchronize(c->pinned_free[0]));
         HIP_TRY(hipEventSynchronize(c->pinned_free[1]));
         fill_image(c, (uint8_t*)c->pinned[0], im, arena, off16, len, n);
+        const int tile0 = c->tile_override ? c->tile_override : tile_for(im.sum_len / n, true, im.max_len);
+        const u64 waves = (n + (u32)tile0 - 1u) / (u32)tile0;
+        if (im.total <= c->zero_copy_bytes && (im.total <= kInPlaceOneWave || im.total <= waves * kInPlaceOneWave || waves >= 8u)) {
+            // a drained queue of a few to a few thousand frames: the kernel reads the image straight out of the pinned
+            // host buffer and writes the results into the other one (both are mapped into the device's address
+            // space), which saves the two copy commands -- at this size their fixed cost is most of the call.  Not
+            // for a few jumbo frames: one wave pulling 100 KiB across the link row by row is slower than the copy.
+            if ((rc = launch_verify(c->s_comp, image_batch((const uint8_t*)c->pinned_dev[0], im, off16 != nullptr, stride16, n), iface, tile0,
+                                    (u32*)c->pinned_dev[1])))
+                return rc;
+            HIP_TRY(hipStreamSynchronize(c->s_comp));
+            const u32* res = (const u32*)c->pinned[1];
+            memcpy(out, res, (size_t)n * 4u);
+            // so few results are counted here rather than by a launch of their own
+            for (u32 i = 0; i < n; i++) {
+                const u32 v = (res[i] >> 16) & 0xffu;
+                c->host_counts[v < UNET_V_COUNT ? v : 0u]++;  // as k_count_verdicts does
+            }
+            return UNET_OK;
+        }
         uint8_t* dev = (uint8_t*)c->d_arena.p;
         HIP_TRY(hipMemcpyAsync(dev, c->pinned[0], im.total, hipMemcpyHostToDevice, c->s_comp));
         u32* d_out = (u32*)(dev + res_at);
@@ -1018,7 +1055,11 @@ int unet_counters(unet_ctx* c, uint64_t* out, int reset) {
     for (auto& sl : c->slot) HIP_TRY(hipStreamSynchronize(sl.s));
     static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "counter width");
     HIP_TRY(hipMemcpy(out, c->d_counts, UNET_V_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset(c->d_counts, 0, UNET_V_COUNT * sizeof(uint64_t)));
+    for (u32 v = 0; v < UNET_V_COUNT; v++) out[v] += c->host_counts[v];  // batches small enough to be counted on the host
+    if (reset) {
+        HIP_TRY(hipMemset(c->d_counts, 0, UNET_V_COUNT * sizeof(uint64_t)));
+        for (u32 v = 0; v < UNET_V_COUNT; v++) c->host_counts[v] = 0;
+    }
     return UNET_OK;
 }
 
