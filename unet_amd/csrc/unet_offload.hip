@@ -196,6 +196,8 @@ struct unet_ctx {
         hipStream_t s = nullptr;
         hipEvent_t done = nullptr;
         void* pin = nullptr;
+        void* pin_dev = nullptr;   // the same buffer as the device sees it
+        bool in_place = false;     // this batch is judged on the pinned image itself
         size_t pin_cap = 0;
         DevBuf dev;
         bool busy = false;
@@ -340,6 +342,22 @@ int upload_batch(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const 
     b->len = (const u32*)c->d_len.p;
     b->n = n;
     return UNET_OK;
+}
+
+// Is a staging image better read by the kernel where it lies (pinned host memory, across the host link) than copied
+// to HBM first?  Yes for a drained queue of a few to a few thousand frames, where the two copy commands' fixed cost
+// is most of the call; no for a few jumbo frames: one wave pulling 100 KiB across the link row by row is slower than
+// the copy engine.
+inline bool read_in_place(const unet_ctx* c, u64 image_bytes, u32 n, int records_per_wave) {
+    const u64 waves = (n + (u32)records_per_wave - 1u) / (u32)records_per_wave;
+    return image_bytes <= c->zero_copy_bytes && (image_bytes <= kInPlaceOneWave || image_bytes <= waves * kInPlaceOneWave || waves >= 8u);
+}
+// The verdicts of a batch judged in place are counted here rather than by a launch of their own.
+inline void count_on_host(unet_ctx* c, const u32* res, u32 n) {
+    for (u32 i = 0; i < n; i++) {
+        const u32 v = (res[i] >> 16) & 0xffu;
+        c->host_counts[v < UNET_V_COUNT ? v : 0u]++;  // as k_count_verdicts does
+    }
 }
 
 int launch_verify(hipStream_t s, const Batch& b_in, const unet_iface* iface, int records_per_wave, u32* d_out) {
@@ -718,23 +736,15 @@ int unet_verify(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const u
         HIP_TRY(hipEventSynchronize(c->pinned_free[1]));
         fill_image(c, (uint8_t*)c->pinned[0], im, arena, off16, len, n);
         const int tile0 = c->tile_override ? c->tile_override : tile_for(im.sum_len / n, true, im.max_len);
-        const u64 waves = (n + (u32)tile0 - 1u) / (u32)tile0;
-        if (im.total <= c->zero_copy_bytes && (im.total <= kInPlaceOneWave || im.total <= waves * kInPlaceOneWave || waves >= 8u)) {
-            // a drained queue of a few to a few thousand frames: the kernel reads the image straight out of the pinned
-            // host buffer and writes the results into the other one (both are mapped into the device's address
-            // space), which saves the two copy commands -- at this size their fixed cost is most of the call.  Not
-            // for a few jumbo frames: one wave pulling 100 KiB across the link row by row is slower than the copy.
+        if (read_in_place(c, im.total, n, tile0)) {
+            // the kernel reads the image straight out of the pinned host buffer and writes the results into the
+            // other one (both are mapped into the device's address space): one launch, one wait, no copy command
             if ((rc = launch_verify(c->s_comp, image_batch((const uint8_t*)c->pinned_dev[0], im, off16 != nullptr, stride16, n), iface, tile0,
                                     (u32*)c->pinned_dev[1])))
                 return rc;
             HIP_TRY(hipStreamSynchronize(c->s_comp));
-            const u32* res = (const u32*)c->pinned[1];
-            memcpy(out, res, (size_t)n * 4u);
-            // so few results are counted here rather than by a launch of their own
-            for (u32 i = 0; i < n; i++) {
-                const u32 v = (res[i] >> 16) & 0xffu;
-                c->host_counts[v < UNET_V_COUNT ? v : 0u]++;  // as k_count_verdicts does
-            }
+            memcpy(out, c->pinned[1], (size_t)n * 4u);
+            count_on_host(c, (const u32*)c->pinned[1], n);
             return UNET_OK;
         }
         uint8_t* dev = (uint8_t*)c->d_arena.p;
@@ -787,18 +797,27 @@ int unet_verify_async(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, c
         hipError_t e = hipHostMalloc(&sl.pin, want, hipHostMallocDefault);
         if (e != hipSuccess) return fail(UNET_E_NOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
         sl.pin_cap = want;
+        HIP_TRY(hipHostGetDevicePointer(&sl.pin_dev, sl.pin, 0));
     }
-    if ((rc = ensure(c, sl.dev, need))) return rc;
+    const int tile = c->tile_override ? c->tile_override : tile_for(im.sum_len / n, true, im.max_len);
+    sl.in_place = read_in_place(c, im.total, n, tile);
+    if (!sl.in_place && (rc = ensure(c, sl.dev, need))) return rc;
     // the caller's buffers are free again when this returns: everything the GPU reads sits in the pinned image
     fill_image(c, (uint8_t*)sl.pin, im, arena, off16, len, n);
-    uint8_t* dev = (uint8_t*)sl.dev.p;
-    HIP_TRY(hipMemcpyAsync(dev, sl.pin, im.total, hipMemcpyHostToDevice, sl.s));
-    u32* d_out = (u32*)(dev + res_at);
-    const int tile = c->tile_override ? c->tile_override : tile_for(im.sum_len / n, true, im.max_len);
-    if ((rc = launch_verify(sl.s, image_batch(dev, im, off16 != nullptr, stride16, n), iface, tile, d_out))) return rc;
-    HIP_TRY(hipMemcpyAsync((uint8_t*)sl.pin + res_at, d_out, (size_t)n * 4u, hipMemcpyDeviceToHost, sl.s));
-    HIP_TRY(hipEventRecord(sl.done, sl.s));
-    if ((rc = count_into_ctx(c, sl.s, d_out, n))) return rc;
+    if (sl.in_place) {
+        // (see unet_verify: the kernel works on the pinned image itself)
+        const uint8_t* hd = (const uint8_t*)sl.pin_dev;
+        if ((rc = launch_verify(sl.s, image_batch(hd, im, off16 != nullptr, stride16, n), iface, tile, (u32*)((uint8_t*)sl.pin_dev + res_at)))) return rc;
+        HIP_TRY(hipEventRecord(sl.done, sl.s));
+    } else {
+        uint8_t* dev = (uint8_t*)sl.dev.p;
+        HIP_TRY(hipMemcpyAsync(dev, sl.pin, im.total, hipMemcpyHostToDevice, sl.s));
+        u32* d_out = (u32*)(dev + res_at);
+        if ((rc = launch_verify(sl.s, image_batch(dev, im, off16 != nullptr, stride16, n), iface, tile, d_out))) return rc;
+        HIP_TRY(hipMemcpyAsync((uint8_t*)sl.pin + res_at, d_out, (size_t)n * 4u, hipMemcpyDeviceToHost, sl.s));
+        HIP_TRY(hipEventRecord(sl.done, sl.s));
+        if ((rc = count_into_ctx(c, sl.s, d_out, n))) return rc;
+    }
     sl.busy = true;
     sl.seq = (sl.seq + 1u) & 0xffffffu;
     sl.n = n;
@@ -817,6 +836,7 @@ int unet_wait(unet_ctx* c, unet_ticket ticket) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventSynchronize(sl.done));
     memcpy(sl.out, (const uint8_t*)sl.pin + sl.res_at, (size_t)sl.n * 4u);
+    if (sl.in_place) count_on_host(c, (const u32*)((const uint8_t*)sl.pin + sl.res_at), sl.n);
     sl.busy = false;
     return UNET_OK;
 }
