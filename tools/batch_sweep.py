@@ -118,6 +118,22 @@ def main():
     data = bytes(range(256)) * 5 + bytes(220)
     print(json.dumps({"config": "calculate_checksum on one 1500-byte buffer", "oracle_us_via_ctypes": round(timed(lambda: O.calculate_checksum(data, 0), min_reps=1000), 3),
                       "unet_csum_us": round(timed(lambda: ctx.calculate_checksum(data, 0)), 2)}), flush=True)
+    # transmit side, host pointers: the echo replies / datagrams of one drained queue
+    from unet_amd._ffi import TX_DESC_DTYPE, tx_out_layout
+    lo = unet_amd.Iface("192.0.2.2", "255.255.255.0", mac=tap_mac, mode=1)
+    for n, size in ((1, 56), (16, 56), (256, 56), (16, 1472), (256, 1472), (4096, 1472)):
+        rng = np.random.default_rng(n + size)
+        payloads = [rng.integers(0, 256, size=size, dtype=np.uint8).tobytes() for _ in range(n)]
+        pa, po, pl = unet_amd.pack_arena(payloads)
+        desc = np.zeros(n, dtype=TX_DESC_DTYPE)
+        desc["src"] = lo.unicast
+        desc["dst"] = 0xC0000201
+        desc["proto"] = np.where(np.arange(n) % 2 == 0, 1, 17)
+        desc["l4a"] = 0x0800
+        ooff, obytes = tx_out_layout(pl, lo.mode)
+        print(json.dumps({"tx_build": f"{n} payloads of {size} bytes -> Ethernet frames",
+                          "unet_tx_build_us": round(timed(lambda: ctx.tx_build(pa, po, pl, desc, lo)), 2),
+                          "oracle_1core_us": round(timed(lambda: O.tx_build_batch(pa, po, pl, desc, lo, ooff, obytes), min_s=0.2, min_reps=2), 2)}), flush=True)
     ctx.close()
 
 

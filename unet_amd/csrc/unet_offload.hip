@@ -184,6 +184,7 @@ struct unet_ctx {
     CopyPool* pool = nullptr;
     int tile_override = 0;        // UNET_TILE, read once at unet_open
     int tx_tile_override = 0;     // UNET_TX_TILE (4, 8, 16, 32, 64), read once at unet_open
+    int tx_tile_once = 0;         // packets per wave for the next unet_tx_build_dev call only (set by unet_tx_build)
     bool hdr_plain = false;       // UNET_HDR_PLAIN, read once at unet_open
     u32 mean_len_hint = 0;        // unet_hint_mean_len
     bool len_known = false;       // set by the host-pointer entry points around their *_dev call
@@ -279,6 +280,7 @@ inline bool arena_too_small(u64 arena_bytes) { return arena_bytes < 16; }
 // ones).  So it is chosen when the longest record is known to be that short, or -- lengths unseen -- when the
 // mean is so low that hardly any record can be longer.
 constexpr u64 kInPlaceOneWave = 64u << 10;  // what one wave may be left to read across the host link (see unet_verify)
+constexpr u64 kTxInPlaceBytes = 1u << 20;    // unet_tx_build: input and output images up to this size stay in pinned host memory
 constexpr u64 kShortMax = 64;
 inline int tile_for(u64 mean_len, bool max_known, u64 max_len) {
     if (mean_len > 1024) return 16;  // (records of exactly 1 KiB are still read faster as a stream, by 32-record tiles)
@@ -352,6 +354,8 @@ inline bool read_in_place(const unet_ctx* c, u64 image_bytes, u32 n, int records
     const u64 waves = (n + (u32)records_per_wave - 1u) / (u32)records_per_wave;
     return image_bytes <= c->zero_copy_bytes && (image_bytes <= kInPlaceOneWave || image_bytes <= waves * kInPlaceOneWave || waves >= 8u);
 }
+// Long records read in place: four to a wave instead of sixteen, so that more waves pull on the link at once.
+inline int in_place_tile(int tile) { return tile == 16 ? 4 : tile; }
 // The verdicts of a batch judged in place are counted here rather than by a launch of their own.
 inline void count_on_host(unet_ctx* c, const u32* res, u32 n) {
     for (u32 i = 0; i < n; i++) {
@@ -736,10 +740,11 @@ int unet_verify(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const u
         HIP_TRY(hipEventSynchronize(c->pinned_free[1]));
         fill_image(c, (uint8_t*)c->pinned[0], im, arena, off16, len, n);
         const int tile0 = c->tile_override ? c->tile_override : tile_for(im.sum_len / n, true, im.max_len);
-        if (read_in_place(c, im.total, n, tile0)) {
+        const int tile_here = in_place_tile(tile0);
+        if (read_in_place(c, im.total, n, tile_here)) {
             // the kernel reads the image straight out of the pinned host buffer and writes the results into the
             // other one (both are mapped into the device's address space): one launch, one wait, no copy command
-            if ((rc = launch_verify(c->s_comp, image_batch((const uint8_t*)c->pinned_dev[0], im, off16 != nullptr, stride16, n), iface, tile0,
+            if ((rc = launch_verify(c->s_comp, image_batch((const uint8_t*)c->pinned_dev[0], im, off16 != nullptr, stride16, n), iface, tile_here,
                                     (u32*)c->pinned_dev[1])))
                 return rc;
             HIP_TRY(hipStreamSynchronize(c->s_comp));
@@ -800,14 +805,15 @@ int unet_verify_async(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, c
         HIP_TRY(hipHostGetDevicePointer(&sl.pin_dev, sl.pin, 0));
     }
     const int tile = c->tile_override ? c->tile_override : tile_for(im.sum_len / n, true, im.max_len);
-    sl.in_place = read_in_place(c, im.total, n, tile);
+    const int tile_here = in_place_tile(tile);
+    sl.in_place = read_in_place(c, im.total, n, tile_here);
     if (!sl.in_place && (rc = ensure(c, sl.dev, need))) return rc;
     // the caller's buffers are free again when this returns: everything the GPU reads sits in the pinned image
     fill_image(c, (uint8_t*)sl.pin, im, arena, off16, len, n);
     if (sl.in_place) {
         // (see unet_verify: the kernel works on the pinned image itself)
         const uint8_t* hd = (const uint8_t*)sl.pin_dev;
-        if ((rc = launch_verify(sl.s, image_batch(hd, im, off16 != nullptr, stride16, n), iface, tile, (u32*)((uint8_t*)sl.pin_dev + res_at)))) return rc;
+        if ((rc = launch_verify(sl.s, image_batch(hd, im, off16 != nullptr, stride16, n), iface, tile_here, (u32*)((uint8_t*)sl.pin_dev + res_at)))) return rc;
         HIP_TRY(hipEventRecord(sl.done, sl.s));
     } else {
         uint8_t* dev = (uint8_t*)sl.dev.p;
@@ -983,6 +989,8 @@ int unet_tx_build_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload_aren
                        d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status)
     int tile = pick_tile(ctx, payload_arena_bytes, payload_stride16, n);
     if (tile > 32 && tile < 64) tile = 32;  // (the in-between sizes exist for the receive-side kernels only)
+    if (ctx->tx_tile_once) tile = ctx->tx_tile_once;
+    ctx->tx_tile_once = 0;
     if (ctx->tx_tile_override) tile = ctx->tx_tile_override;
     if (iface->mode == UNET_MODE_L2) {
         if (tile == 8) UNET_TX_LAUNCH(MODE_L2, 8);
@@ -1030,6 +1038,42 @@ int unet_tx_build(unet_ctx* c, const uint8_t* payload_arena, uint64_t payload_ar
     if (rc) return rc;
     if (out_arena_bytes < need) return fail(UNET_E_RANGE, "output arena of %llu bytes, need %llu", (unsigned long long)out_arena_bytes, (unsigned long long)need);
     HIP_TRY(hipSetDevice(c->device));
+    {
+        // A few packets (the echo replies and datagrams of one drained queue): everything the kernel reads goes into
+        // one pinned image [lengths | offsets | output offsets | descriptors | payloads] that it reads in place, and
+        // it writes [output lengths | status | packets] into the other pinned buffer: one launch, one wait.
+        Image im;
+        if ((rc = plan_image(payload_arena_bytes, payload_off16, payload_stride16, payload_len, n, &im))) return rc;
+        const u64 tab = ((u64)n * 4u + 15u) & ~15ull, dtab = ((u64)n * sizeof(unet_tx_desc) + 15u) & ~15ull;
+        const u64 in_off = tab, in_ooff = 2u * tab, in_desc = 3u * tab, in_arena = in_desc + dtab, in_total = in_arena + im.used;
+        const u64 o_len = 0, o_st = tab, o_arena = (tab + (((u64)n + 15u) & ~15ull) + 255u) & ~255ull, o_total = o_arena + need;
+        if (in_total <= kTxInPlaceBytes && o_total <= kTxInPlaceBytes && in_total <= c->zero_copy_bytes) {
+            HIP_TRY(hipEventSynchronize(c->pinned_free[0]));
+            HIP_TRY(hipEventSynchronize(c->pinned_free[1]));
+            uint8_t* pi = (uint8_t*)c->pinned[0];
+            uint8_t* po = (uint8_t*)c->pinned[1];
+            memcpy(pi, payload_len, (size_t)n * 4u);
+            if (payload_off16) memcpy(pi + in_off, payload_off16, (size_t)n * 4u);
+            memcpy(pi + in_ooff, out_off16, (size_t)n * 4u);
+            memcpy(pi + in_desc, desc, (size_t)n * sizeof(unet_tx_desc));
+            memcpy(pi + in_arena, payload_arena, (size_t)(im.used < payload_arena_bytes ? im.used : payload_arena_bytes));
+            memset(po, 0, o_total);  // refused packets and pad bytes read as zeros
+            const uint8_t* di = (const uint8_t*)c->pinned_dev[0];
+            uint8_t* dout = (uint8_t*)c->pinned_dev[1];
+            LenScope hint(c, (u32)(im.sum_len / n), im.max_len);
+            // payloads that take a whole wave each: eight per wave rather than sixteen, so that more waves pull on the link
+            if (im.sum_len / n > 1024u) c->tx_tile_once = 8;
+            rc = unet_tx_build_dev(c, nullptr, di + in_arena, im.used, payload_off16 ? (const uint32_t*)(di + in_off) : nullptr, payload_stride16,
+                                   (const uint32_t*)di, (const unet_tx_desc*)(di + in_desc), n, iface, dout + o_arena, need,
+                                   (const uint32_t*)(di + in_ooff), (uint32_t*)(dout + o_len), dout + o_st);
+            if (rc) return rc;
+            HIP_TRY(hipStreamSynchronize(c->s_comp));
+            memcpy(out_len, po + o_len, (size_t)n * 4u);
+            if (status) memcpy(status, po + o_st, n);
+            memcpy(out_arena, po + o_arena, need);
+            return UNET_OK;
+        }
+    }
     Batch b;
     u32 mean = 0, maxlen = 0;
     if ((rc = upload_batch(c, payload_arena, payload_arena_bytes, payload_off16, payload_stride16, payload_len, n, &b, &mean, &maxlen))) return rc;
