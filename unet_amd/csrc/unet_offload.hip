@@ -184,6 +184,7 @@ struct unet_ctx {
     CopyPool* pool = nullptr;
     int tile_override = 0;        // UNET_TILE, read once at unet_open
     int tx_tile_override = 0;     // UNET_TX_TILE (4, 8, 16, 32, 64), read once at unet_open
+    int tile_once = 0;            // records per wave for the launch a host-pointer entry point is about to make
     int tx_tile_once = 0;         // packets per wave for the next unet_tx_build_dev call only (set by unet_tx_build)
     bool hdr_plain = false;       // UNET_HDR_PLAIN, read once at unet_open
     u32 mean_len_hint = 0;        // unet_hint_mean_len
@@ -299,6 +300,7 @@ inline int kernel_tile(int tile) { return tile <= 16 ? 16 : (tile <= 32 ? 32 : 6
 // given (unet_hint_mean_len), else the fixed stride (which also bounds the length), else arena_bytes / n (right
 // for packed arenas).  The host-pointer entry points pass the true mean and maximum.
 inline int pick_tile(const unet_ctx* c, u64 arena_bytes, u32 stride16, u32 n) {
+    if (c->tile_once) return c->tile_once;  // set around one launch by a host-pointer entry point
     if (c->tile_override) return c->tile_override;
     if (c->len_known) return tile_for(c->mean_len_known, true, c->max_len_known);
     if (c->mean_len_hint) return tile_for(c->mean_len_hint, false, 0);
@@ -927,6 +929,23 @@ int unet_checksum_fields_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena
     return UNET_OK;
 }
 
+namespace {
+// Stores the checksum values the GPU computed into the caller's packets (those whose status is 0).
+void patch_fields(uint8_t* arena, const uint32_t* off16, uint32_t stride16, uint32_t n, const unet_tx_fields* fields, const uint8_t* st,
+                  uint8_t* status) {
+    for (u32 i = 0; i < n; i++) {
+        if (status) status[i] = st[i];
+        if (st[i] != 0) continue;
+        uint8_t* p = arena + (off16 ? (u64)off16[i] : (u64)i * stride16) * 16u;
+        p[10] = (uint8_t)(fields[i].ip_csum >> 8);
+        p[11] = (uint8_t)fields[i].ip_csum;
+        uint8_t* f = p + (p[9] == 17 ? 26 : 22);  // UDP checksum field / ICMP checksum field behind a 20-byte header
+        f[0] = (uint8_t)(fields[i].l4_csum >> 8);
+        f[1] = (uint8_t)fields[i].l4_csum;
+    }
+}
+}  // namespace
+
 int unet_generate(unet_ctx* c, uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16, uint32_t stride16,
                   const uint32_t* len, uint32_t n, uint8_t* status) {
     if (!c) return fail(UNET_E_INVAL, "null context");
@@ -934,9 +953,32 @@ int unet_generate(unet_ctx* c, uint8_t* arena, uint64_t arena_bytes, const uint3
     if (!arena || !len) return fail(UNET_E_INVAL, "null argument");
     if (!off16 && stride16 == 0) return fail(UNET_E_INVAL, "need an offset table or a non-zero stride");
     HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if (arena_bytes + 2ull * n * 4u + 32u <= kStageBytes && (u64)n * 5u + 16u <= kStageBytes) {
+        // a few packets: the kernel reads them where the staging image lies and leaves values and status in the
+        // other pinned buffer (see unet_verify)
+        Image im;
+        if ((rc = plan_image(arena_bytes, off16, stride16, len, n, &im))) return rc;
+        const int tile = in_place_tile(c->tile_override ? c->tile_override : tile_for(im.sum_len / n, true, im.max_len));
+        if (read_in_place(c, im.total, n, tile)) {
+            HIP_TRY(hipEventSynchronize(c->pinned_free[0]));
+            HIP_TRY(hipEventSynchronize(c->pinned_free[1]));
+            fill_image(c, (uint8_t*)c->pinned[0], im, arena, off16, len, n);
+            const uint8_t* di = (const uint8_t*)c->pinned_dev[0];
+            const u64 st_at = ((u64)n * 4u + 15u) & ~15ull;
+            c->tile_once = tile;
+            rc = unet_checksum_fields_dev(c, nullptr, di + im.at_arena, im.used, off16 ? (const uint32_t*)(di + im.at_off) : nullptr, stride16,
+                                          (const uint32_t*)di, n, (unet_tx_fields*)c->pinned_dev[1], (uint8_t*)c->pinned_dev[1] + st_at);
+            c->tile_once = 0;
+            if (rc) return rc;
+            HIP_TRY(hipStreamSynchronize(c->s_comp));
+            patch_fields(arena, off16, stride16, n, (const unet_tx_fields*)c->pinned[1], (const uint8_t*)c->pinned[1] + st_at, status);
+            return UNET_OK;
+        }
+    }
     Batch b;
     u32 mean = 0, maxlen = 0;
-    int rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b, &mean, &maxlen);
+    rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b, &mean, &maxlen);
     LenScope hint(c, mean, maxlen);
     if (rc) return rc;
     // the GPU computes the two checksum values per packet; only those 4 bytes (and the status) travel
@@ -956,16 +998,7 @@ int unet_generate(unet_ctx* c, uint8_t* arena, uint64_t arena_bytes, const uint3
     }
     if ((rc = d2h_sync(c, fields.data(), d_fields, (size_t)n * 4))) return rc;
     if ((rc = d2h_sync(c, st.data(), d_status, (size_t)n))) return rc;
-    for (u32 i = 0; i < n; i++) {
-        if (status) status[i] = st[i];
-        if (st[i] != 0) continue;
-        uint8_t* p = arena + (off16 ? (u64)off16[i] : (u64)i * stride16) * 16u;
-        p[10] = (uint8_t)(fields[i].ip_csum >> 8);
-        p[11] = (uint8_t)fields[i].ip_csum;
-        uint8_t* f = p + (p[9] == 17 ? 26 : 22);  // UDP checksum field / ICMP checksum field behind a 20-byte header
-        f[0] = (uint8_t)(fields[i].l4_csum >> 8);
-        f[1] = (uint8_t)fields[i].l4_csum;
-    }
+    patch_fields(arena, off16, stride16, n, fields.data(), st.data(), status);
     return UNET_OK;
 }
 
