@@ -1,5 +1,5 @@
-"""Randomised parity soak: batches with random length mixes, layouts, modes and contents through unet_verify,
-unet_csum_batch, unet_generate and unet_tx_build, every result against the CPU oracle.  Not collected by pytest (it runs for as
+"""Randomised parity soak: batches with random length mixes, layouts, modes and contents through unet_verify (and its
+static and asynchronous forms), unet_csum_batch, unet_generate and unet_tx_build, every result against the CPU oracle.  Not collected by pytest (it runs for as
 long as it is told to); tests/test_fuzz_short.py runs a few rounds of it.
 
 usage: python tests/fuzz_parity.py [seconds] [first seed]"""
@@ -89,6 +89,14 @@ def one_round(ctx, seed):
     exp = O.recv_batch(arena, off16, lens, ifc, stride16=stride16)
     bad = np.nonzero(got != exp)[0]
     assert bad.size == 0, ("verify", tag, bad[:5], got[bad[:5]], exp[bad[:5]], lens[bad[:5]])
+    # the other two host-pointer forms of the same call
+    if n <= 65536 and arena.nbytes <= (8 << 20):
+        assert np.array_equal(ctx.verify_static(arena, off16, lens, ifc, stride16=stride16), exp), ("verify_static", tag)
+    t, out = ctx.verify_async(arena, off16, lens, ifc, stride16=stride16)
+    t2, out2 = ctx.verify_async(arena, off16, lens, ifc, stride16=stride16)
+    ctx.wait(t)
+    ctx.wait(t2)
+    assert np.array_equal(out, exp) and np.array_equal(out2, exp), ("verify_async", tag)
     seeds = rng.integers(0, 65536, size=n).astype(np.uint16)
     g = ctx.csum_batch(arena, off16, lens, seeds, stride16=stride16)
     e = O.csum_batch(arena, off16, lens, seeds, stride16=stride16)
