@@ -1,5 +1,5 @@
 """Randomised parity soak: batches with random length mixes, layouts, modes and contents through unet_verify (and its
-static and asynchronous forms), unet_csum_batch, unet_generate and unet_tx_build, every result against the CPU oracle.  Not collected by pytest (it runs for as
+static and asynchronous forms), unet_ipv4_validate, unet_csum_batch, unet_generate and unet_tx_build, every result against the CPU oracle.  Not collected by pytest (it runs for as
 long as it is told to); tests/test_fuzz_short.py runs a few rounds of it.
 
 usage: python tests/fuzz_parity.py [seconds] [first seed]"""
@@ -97,6 +97,13 @@ def one_round(ctx, seed):
     ctx.wait(t)
     ctx.wait(t2)
     assert np.array_equal(out, exp) and np.array_equal(out2, exp), ("verify_async", tag)
+    # bare 20-byte headers: the generator's (valid and faulty) with a few random ones among them
+    nh = int(rng.choice([1, 3, 255, 256, 257, 1000, 5000]))
+    hdrs, _, _ = unet_amd.synth_host(unet_amd.SYNTH_IPV4_HDR20, int(rng.integers(1, 2**31)), int(rng.integers(0, 2**20)), nh, ifc)
+    hdrs = hdrs[:nh * 20].copy()
+    noisy = rng.random(nh) < 0.1
+    hdrs.reshape(nh, 20)[noisy] = rng.integers(0, 256, size=(int(noisy.sum()), 20), dtype=np.uint8)
+    assert np.array_equal(ctx.ipv4_validate(hdrs, ifc), O.ipv4_validate_batch(hdrs, ifc.ext_tcp)), ("ipv4_validate", tag, nh)
     seeds = rng.integers(0, 65536, size=n).astype(np.uint16)
     g = ctx.csum_batch(arena, off16, lens, seeds, stride16=stride16)
     e = O.csum_batch(arena, off16, lens, seeds, stride16=stride16)

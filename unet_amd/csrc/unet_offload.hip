@@ -697,6 +697,18 @@ int unet_ipv4_validate(unet_ctx* c, const uint8_t* hdrs, uint32_t n, const unet_
     HIP_TRY(hipSetDevice(c->device));
     const size_t bytes = (size_t)n * 20;
     int rc;
+    if (bytes + 16 <= c->zero_copy_bytes && bytes + 16 <= kStageBytes) {
+        // a few headers: judged where the pinned staging buffer lies (see unet_verify)
+        HIP_TRY(hipEventSynchronize(c->pinned_free[0]));
+        HIP_TRY(hipEventSynchronize(c->pinned_free[1]));
+        memcpy(c->pinned[0], hdrs, bytes);
+        memset((uint8_t*)c->pinned[0] + bytes, 0, 16);
+        if ((rc = unet_ipv4_validate_dev(c, nullptr, (const uint8_t*)c->pinned_dev[0], n, iface, (unet_result*)c->pinned_dev[1]))) return rc;
+        HIP_TRY(hipStreamSynchronize(c->s_comp));
+        memcpy(out, c->pinned[1], (size_t)n * 4u);
+        count_on_host(c, (const u32*)c->pinned[1], n);
+        return UNET_OK;
+    }
     if ((rc = ensure(c, c->d_arena, bytes + 16))) return rc;  // device buffer covers the last partial chunk
     if ((rc = ensure(c, c->d_out, (size_t)n * 4))) return rc;
     if ((rc = h2d(c, c->d_arena.p, hdrs, bytes))) return rc;
