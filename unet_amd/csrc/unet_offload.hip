@@ -1092,7 +1092,9 @@ int unet_tx_build(unet_ctx* c, const uint8_t* payload_arena, uint64_t payload_ar
         const u64 tab = ((u64)n * 4u + 15u) & ~15ull, dtab = ((u64)n * sizeof(unet_tx_desc) + 15u) & ~15ull;
         const u64 in_off = tab, in_ooff = 2u * tab, in_desc = 3u * tab, in_arena = in_desc + dtab, in_total = in_arena + im.used;
         const u64 o_len = 0, o_st = tab, o_arena = (tab + (((u64)n + 15u) & ~15ull) + 255u) & ~255ull, o_total = o_arena + need;
-        if (in_total <= kTxInPlaceBytes && o_total <= kTxInPlaceBytes && in_total <= c->zero_copy_bytes) {
+        const bool in_place = in_total <= kTxInPlaceBytes && o_total <= kTxInPlaceBytes && in_total <= c->zero_copy_bytes;
+        if (in_place || (in_total <= kStageBytes && o_total <= kStageBytes)) {
+            // (larger batches that still fit the pinned buffers: the same two images, one copy command each way)
             HIP_TRY(hipEventSynchronize(c->pinned_free[0]));
             HIP_TRY(hipEventSynchronize(c->pinned_free[1]));
             uint8_t* pi = (uint8_t*)c->pinned[0];
@@ -1101,21 +1103,34 @@ int unet_tx_build(unet_ctx* c, const uint8_t* payload_arena, uint64_t payload_ar
             if (payload_off16) memcpy(pi + in_off, payload_off16, (size_t)n * 4u);
             memcpy(pi + in_ooff, out_off16, (size_t)n * 4u);
             memcpy(pi + in_desc, desc, (size_t)n * sizeof(unet_tx_desc));
-            memcpy(pi + in_arena, payload_arena, (size_t)(im.used < payload_arena_bytes ? im.used : payload_arena_bytes));
-            memset(po, 0, o_total);  // refused packets and pad bytes read as zeros
-            const uint8_t* di = (const uint8_t*)c->pinned_dev[0];
-            uint8_t* dout = (uint8_t*)c->pinned_dev[1];
+            c->pool->copy(pi + in_arena, payload_arena, (size_t)(im.used < payload_arena_bytes ? im.used : payload_arena_bytes));
+            const uint8_t* di;
+            uint8_t* dout;
+            if (in_place) {
+                memset(po, 0, o_total);  // refused packets and pad bytes read as zeros
+                di = (const uint8_t*)c->pinned_dev[0];
+                dout = (uint8_t*)c->pinned_dev[1];
+            } else {
+                if ((rc = ensure(c, c->d_arena, in_total))) return rc;
+                if ((rc = ensure(c, c->d_tx, o_total))) return rc;
+                HIP_TRY(hipMemcpyAsync(c->d_arena.p, pi, in_total, hipMemcpyHostToDevice, c->s_comp));
+                HIP_TRY(hipMemsetAsync(c->d_tx.p, 0, o_total, c->s_comp));
+                di = (const uint8_t*)c->d_arena.p;
+                dout = (uint8_t*)c->d_tx.p;
+            }
             LenScope hint(c, (u32)(im.sum_len / n), im.max_len);
-            // payloads that take a whole wave each: eight per wave rather than sixteen, so that more waves pull on the link
-            if (im.sum_len / n > 1024u) c->tx_tile_once = 8;
+            // payloads that take a whole wave each, read across the link: eight per wave rather than sixteen, so that
+            // more waves pull on it
+            if (in_place && im.sum_len / n > 1024u) c->tx_tile_once = 8;
             rc = unet_tx_build_dev(c, nullptr, di + in_arena, im.used, payload_off16 ? (const uint32_t*)(di + in_off) : nullptr, payload_stride16,
                                    (const uint32_t*)di, (const unet_tx_desc*)(di + in_desc), n, iface, dout + o_arena, need,
                                    (const uint32_t*)(di + in_ooff), (uint32_t*)(dout + o_len), dout + o_st);
             if (rc) return rc;
+            if (!in_place) HIP_TRY(hipMemcpyAsync(po, dout, o_total, hipMemcpyDeviceToHost, c->s_comp));
             HIP_TRY(hipStreamSynchronize(c->s_comp));
             memcpy(out_len, po + o_len, (size_t)n * 4u);
             if (status) memcpy(status, po + o_st, n);
-            memcpy(out_arena, po + o_arena, need);
+            c->pool->copy(out_arena, po + o_arena, need);
             return UNET_OK;
         }
     }
