@@ -117,7 +117,7 @@ typedef struct unet_ctx unet_ctx;
 /* Bind a context to one HIP device.  Creates two streams and pinned staging used by the
  * host-pointer entry points.  One context per thread/GPU (thread-compatible, not thread-safe).
  * Host-pointer calls on small batches (staging image up to 4 MiB for unet_verify, unet_verify_async,
- * unet_generate and unet_ipv4_validate, 1 MiB for unet_tx_build, 64 KiB for unet_csum) let the kernel read the pinned staging buffer in
+ * unet_generate, unet_ipv4_validate and unet_csum_batch, 1 MiB for unet_tx_build, 64 KiB for unet_csum) let the kernel read the pinned staging buffer in
  * place across the host link and write its results into pinned memory: one launch and one wait per call, no copy
  * command.  Larger batches are copied to device memory first.  Environment, read once here: UNET_ZERO_COPY_BYTES
  * (that limit; 0 = always copy), UNET_COPY_THREADS (host threads filling the staging buffers, default 4). */

@@ -601,9 +601,32 @@ int unet_csum_batch(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, con
     if (!arena || !len || !out) return fail(UNET_E_INVAL, "null argument");
     if (!off16 && stride16 == 0) return fail(UNET_E_INVAL, "need an offset table or a non-zero stride");
     HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if (arena_bytes + 3ull * n * 4u + 64u <= kStageBytes) {
+        // a few buffers: summed where the staging image [lengths | offsets | arena | seeds] lies (see unet_verify)
+        Image im;
+        if ((rc = plan_image(arena_bytes, off16, stride16, len, n, &im))) return rc;
+        const int tile = in_place_tile(c->tile_override ? c->tile_override : tile_for(im.sum_len / n, true, im.max_len));
+        const u64 seeds_at = (im.total + 15u) & ~15ull, total = seeds_at + (seeds ? (u64)n * 2u : 0u);
+        if (read_in_place(c, total, n, tile)) {
+            HIP_TRY(hipEventSynchronize(c->pinned_free[0]));
+            HIP_TRY(hipEventSynchronize(c->pinned_free[1]));
+            fill_image(c, (uint8_t*)c->pinned[0], im, arena, off16, len, n);
+            if (seeds) memcpy((uint8_t*)c->pinned[0] + seeds_at, seeds, (size_t)n * 2u);
+            const uint8_t* di = (const uint8_t*)c->pinned_dev[0];
+            c->tile_once = tile;
+            rc = unet_csum_batch_dev(c, nullptr, di + im.at_arena, im.used, off16 ? (const uint32_t*)(di + im.at_off) : nullptr, stride16,
+                                     (const uint32_t*)di, seeds ? (const uint16_t*)(di + seeds_at) : nullptr, n, (uint16_t*)c->pinned_dev[1]);
+            c->tile_once = 0;
+            if (rc) return rc;
+            HIP_TRY(hipStreamSynchronize(c->s_comp));
+            memcpy(out, c->pinned[1], (size_t)n * 2u);
+            return UNET_OK;
+        }
+    }
     Batch b;
     u32 mean = 0, maxlen = 0;
-    int rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b, &mean, &maxlen);
+    rc = upload_batch(c, arena, arena_bytes, off16, stride16, len, n, &b, &mean, &maxlen);
     LenScope hint(c, mean, maxlen);
     if (rc) return rc;
     if ((rc = ensure(c, c->d_out, (size_t)n * 2))) return rc;
