@@ -275,7 +275,7 @@ int check_batch(unet_ctx* ctx, const void* arena, const void* off16, u32 stride1
 inline bool arena_too_small(u64 arena_bytes) { return arena_bytes < 16; }
 // Records per wave: long records want short tiles (fine-grained tail of the launch), short records
 // want many lanes busy in the lane-parallel phase.
-// Records per wave.  16 for long records (fine-grained tail of the launch), 32 below 1 KiB, and 64-record tiles
+// Records per wave.  16 down to 1 for long records (about 16 KiB per wave), 32 up to 1 KiB, and 64-record tiles
 // for batches of the shortest records only (at most 64 bytes): their kernel stages a tile's byte range in LDS when
 // it fits 4 KiB and reads any other tile with plain per-lane loops (correct for every length, slow for long
 // ones).  So it is chosen when the longest record is known to be that short, or -- lengths unseen -- when the
@@ -284,7 +284,15 @@ constexpr u64 kInPlaceOneWave = 64u << 10;  // what one wave may be left to read
 constexpr u64 kTxInPlaceBytes = 1u << 20;    // unet_tx_build: input and output images up to this size stay in pinned host memory
 constexpr u64 kShortMax = 64;
 inline int tile_for(u64 mean_len, bool max_known, u64 max_len) {
-    if (mean_len > 1024) return 16;  // (records of exactly 1 KiB are still read faster as a stream, by 32-record tiles)
+    if (mean_len > 1024) {  // (records of exactly 1 KiB are still read faster as a stream, by 32-record tiles)
+        // Long records: about 16 KiB per wave (8, 4, 2 records or 1).  A wave that works through sixteen 9000-byte
+        // records holds its slot for 144 KB; shorter waves keep more of them starting and ending all the time
+        // (2048 B: 6.57 -> 7.0 TB/s, 4096 B: 6.68 -> 7.08, 9000 B: 6.67 -> 6.9).  Up to 1536 bytes sixteen is best.
+        if (mean_len <= 1536) return 16;
+        if (mean_len >= 49152) return 8;  // (the very longest run best eight to a wave: 6.98 vs 6.81 singly)
+        const u64 r = 16384u / mean_len;
+        return r >= 8 ? 8 : (r >= 4 ? 4 : (r >= 2 ? 2 : 1));
+    }
     const bool all_short = max_known ? max_len <= kShortMax : mean_len <= kShortMax;
     if (all_short) return 64;
     // Records of 65..96 bytes, the longest known: the same kernel, with as many records per wave as are sure to
@@ -357,7 +365,7 @@ inline bool read_in_place(const unet_ctx* c, u64 image_bytes, u32 n, int records
     return image_bytes <= c->zero_copy_bytes && (image_bytes <= kInPlaceOneWave || image_bytes <= waves * kInPlaceOneWave || waves >= 8u);
 }
 // Long records read in place: four to a wave instead of sixteen, so that more waves pull on the link at once.
-inline int in_place_tile(int tile) { return tile == 16 ? 4 : tile; }
+inline int in_place_tile(int tile) { return tile <= 16 ? (tile < 4 ? tile : 4) : tile; }
 // The verdicts of a batch judged in place are counted here rather than by a launch of their own.
 inline void count_on_host(unet_ctx* c, const u32* res, u32 n) {
     for (u32 i = 0; i < n; i++) {
@@ -517,7 +525,7 @@ int unet_open(int device_id, unet_ctx** out_ctx) {
     }
     if (const char* t = getenv("UNET_TILE")) {
         const int v = atoi(t);
-        c->tile_override = v <= 16 ? 16 : (v <= 32 ? 32 : 64);
+        c->tile_override = v < 1 ? 1 : (v > 64 ? 64 : v);  // records per wave, any value from 1 to 64
     }
     c->hdr_plain = getenv("UNET_HDR_PLAIN") != nullptr;
     if (const char* z = getenv("UNET_ZERO_COPY_BYTES")) c->zero_copy_bytes = strtoull(z, nullptr, 10);
@@ -1057,6 +1065,7 @@ int unet_tx_build_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload_aren
                        d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status)
     int tile = pick_tile(ctx, payload_arena_bytes, payload_stride16, n);
     if (tile > 32 && tile < 64) tile = 32;  // (the in-between sizes exist for the receive-side kernels only)
+    if (tile < 16) tile = 16;               // (and so do the short tiles of long records)
     if (ctx->tx_tile_once) tile = ctx->tx_tile_once;
     ctx->tx_tile_once = 0;
     if (ctx->tx_tile_override) tile = ctx->tx_tile_override;
