@@ -140,3 +140,26 @@ def test_short_record_tiles_generate(offload):
         exp_arena, exp_status = O.generate_batch(arena, off16, lens, stride16=stride16)
         assert (got_status == exp_status).all(), name
         assert (got_arena == exp_arena).all(), name
+
+
+def test_short_record_tiles_inside_a_batch_of_long_records(offload):
+    """A batch whose mean length makes the library take few records per wave (16, 8, 4, 2 or 1), with runs of short
+    records in it: tiles made only of short records stage their byte range in an LDS area sized for that tile
+    shape (112 chunks with 16 records per wave, where two full rows would be 128)."""
+    ifc = unet_amd.Iface("192.0.2.2", "255.255.255.0", mac=bytes.fromhex("02aabbccddee"), mode=unet_amd.MODE_L3, ext_tcp=True)
+    for long_len, per_block, blocks in ((30000, 2, 25), (65535, 4, 25), (9000, 30, 25), (3000, 60, 25), (20000, 3, 600)):
+        rng = np.random.default_rng(long_len)
+        frames = []
+        short = _packets(rng, 48, ifc, max_total=112)
+        for block in range(blocks):
+            frames += short if blocks > 100 else _packets(rng, 48, ifc, max_total=112)
+            frames += [rng.integers(0, 256, size=long_len, dtype=np.uint8).tobytes() for _ in range(per_block)]
+        arena, off16, lens = unet_amd.pack_arena(frames)
+        assert lens.mean() > 1024
+        for _ in range(3):  # (a neighbouring wave's stores are a race: look more than once)
+            got = offload.verify(arena, off16, lens, ifc)
+            exp = O.recv_batch(arena, off16, lens, ifc)
+            bad = np.nonzero(got != exp)[0]
+            assert bad.size == 0, (long_len, bad[:5], got[bad[:5]], exp[bad[:5]], lens[bad[:5]])
+            seeds = rng.integers(0, 65536, size=len(lens)).astype(np.uint16)
+            assert (offload.csum_batch(arena, off16, lens, seeds) == O.csum_batch(arena, off16, lens, seeds)).all(), long_len

@@ -467,10 +467,12 @@ __device__ __forceinline__ SpanPlan plan_span(const Batch& b, const Tile& t, u32
 // The rows go to LDS, every lane sums its own record; t.my_hdr then points at it in LDS.
 template <int TILE>
 __device__ __forceinline__ u32 span_sums(const SpanPlan& sp, Tile& t, u32x4* __restrict__ park) {
-    if (sp.rows > 0u) park[t.lane] = sp.r0;
-    if (sp.rows > 1u) park[kWave + t.lane] = sp.r1;
-    if (sp.rows > 2u) park[2u * kWave + t.lane] = sp.r2;
-    if (sp.rows > 3u) park[3u * kWave + t.lane] = sp.r3;
+    // (only the chunks of the range: the last row may reach past the wave's LDS area -- with 16-record tiles the
+    // area is 112 chunks, less than two rows)
+    if (sp.rows > 0u && t.lane < sp.span) park[t.lane] = sp.r0;
+    if (sp.rows > 1u && kWave + t.lane < sp.span) park[kWave + t.lane] = sp.r1;
+    if (sp.rows > 2u && 2u * kWave + t.lane < sp.span) park[2u * kWave + t.lane] = sp.r2;
+    if (sp.rows > 3u && 3u * kWave + t.lane < sp.span) park[3u * kWave + t.lane] = sp.r3;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const u32 my_nch = (t.my_len + 15u) >> 4;
