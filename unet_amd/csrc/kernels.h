@@ -467,12 +467,14 @@ __device__ __forceinline__ SpanPlan plan_span(const Batch& b, const Tile& t, u32
 // The rows go to LDS, every lane sums its own record; t.my_hdr then points at it in LDS.
 template <int TILE>
 __device__ __forceinline__ u32 span_sums(const SpanPlan& sp, Tile& t, u32x4* __restrict__ park) {
-    // (only the chunks of the range: the last row may reach past the wave's LDS area -- with 16-record tiles the
-    // area is 112 chunks, less than two rows)
-    if (sp.rows > 0u && t.lane < sp.span) park[t.lane] = sp.r0;
-    if (sp.rows > 1u && kWave + t.lane < sp.span) park[kWave + t.lane] = sp.r1;
-    if (sp.rows > 2u && 2u * kWave + t.lane < sp.span) park[2u * kWave + t.lane] = sp.r2;
-    if (sp.rows > 3u && 3u * kWave + t.lane < sp.span) park[3u * kWave + t.lane] = sp.r3;
+    // With 16-record tiles the wave's LDS area is 112 chunks, less than two rows: there only the chunks of the range
+    // are stored.  (The 256 chunks of the larger tiles hold four whole rows; testing there as well costs them 16
+    // registers and two waves per SIMD.)
+    constexpr bool kWholeRows = TileGeom<TILE>::kPark >= 4u * kWave;
+    if (sp.rows > 0u && (kWholeRows || t.lane < sp.span)) park[t.lane] = sp.r0;
+    if (sp.rows > 1u && (kWholeRows || kWave + t.lane < sp.span)) park[kWave + t.lane] = sp.r1;
+    if (sp.rows > 2u && (kWholeRows || 2u * kWave + t.lane < sp.span)) park[2u * kWave + t.lane] = sp.r2;
+    if (sp.rows > 3u && (kWholeRows || 3u * kWave + t.lane < sp.span)) park[3u * kWave + t.lane] = sp.r3;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const u32 my_nch = (t.my_len + 15u) >> 4;
