@@ -25,6 +25,10 @@ LENGTH_CLASSES = [
     lambda r, n: np.where(r.random(n) < 0.01, 65535, r.integers(40, 400, size=n)),
     lambda r, n: np.full(n, int(r.integers(1, 2100))),
     lambda r, n: np.full(n, int(r.choice([64, 80, 96, 112, 128, 256, 512, 1024, 1040, 1504]))),
+    # batches whose mean makes the library take few records per wave, with short records in them
+    lambda r, n: np.where(r.random(n) < 0.1, r.choice([3000, 9000, 30000, 65535], size=n), r.integers(20, 120, size=n)),
+    lambda r, n: np.where(np.arange(n) % int(r.integers(17, 70)) == 0, int(r.choice([20000, 40000, 65535])), r.integers(1, 113, size=n)),
+    lambda r, n: r.choice([1100, 1300, 1536, 1537, 2048, 2049, 4096, 8192, 8193, 16384, 49151, 49152], size=n),
 ]
 
 
