@@ -120,7 +120,8 @@ typedef struct unet_ctx unet_ctx;
  * unet_generate, unet_ipv4_validate and unet_csum_batch, 1 MiB for unet_tx_build, 64 KiB for unet_csum) let the kernel read the pinned staging buffer in
  * place across the host link and write its results into pinned memory: one launch and one wait per call, no copy
  * command.  Larger batches are copied to device memory first.  Environment, read once here: UNET_ZERO_COPY_BYTES
- * (that limit; 0 = always copy), UNET_COPY_THREADS (host threads filling the staging buffers, default 4). */
+ * (that limit; 0 = always copy), UNET_COPY_THREADS (host threads filling the staging buffers, default 4), and for
+ * experiments UNET_TILE / UNET_TX_TILE (records / packets per wave, overriding the library's choice by record size). */
 int unet_open(int device_id, unet_ctx** out_ctx);
 void unet_close(unet_ctx* ctx);
 const char* unet_last_error(void);
