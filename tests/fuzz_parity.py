@@ -1,6 +1,7 @@
 """Randomised parity soak: batches with random length mixes, layouts, modes and contents through unet_verify (and its
 static and asynchronous forms), unet_ipv4_validate, unet_csum_batch, unet_generate and unet_tx_build, every result against the CPU oracle.  Not collected by pytest (it runs for as
-long as it is told to); tests/test_fuzz_short.py runs a few rounds of it.
+long as it is told to); tests/test_fuzz_short.py runs a few rounds of it.  dev_round sends a batch through the device-pointer entry
+points, where the library chooses records per wave from the arena size, the stride or a caller's hint instead of from the lengths.
 
 usage: python tests/fuzz_parity.py [seconds] [first seed]"""
 import os
@@ -151,6 +152,53 @@ def tx_round(ctx, seed):
     return tag
 
 
+def dev_round(ctx, seed):
+    """The device-pointer forms on a batch already in device memory, with no hint, a true one or a wrong one."""
+    import torch
+    rng = np.random.default_rng(seed)
+    mode = unet_amd.MODE_L2 if rng.random() < 0.3 else unet_amd.MODE_L3
+    ifc = unet_amd.Iface("192.0.2.2", "255.255.255.0", mac=bytes.fromhex("02aabbccddee"), mode=mode, ext_tcp=bool(rng.random() < 0.7))
+    n = int(rng.choice([1, 7, 8, 9, 16, 33, 64, 65, 129, 500, 3000]))
+    frames = make_frames(rng, n, ifc)
+    arena, off16, stride16, lens, how = layout(rng, frames)
+    hint = int(rng.choice([0, 0, max(1, int(lens.mean())), 40, 300, 1500, 9000, 60000]))
+    tag = (seed, n, mode, how, int(lens.max()), round(float(lens.mean()), 1), hint)
+    dev = torch.device("cuda:0")
+    d_arena = torch.from_numpy(arena).to(dev)
+    d_off = None if off16 is None else torch.from_numpy(off16.view(np.int32)).to(dev)
+    p_off = 0 if d_off is None else d_off.data_ptr()
+    d_len = torch.from_numpy(lens.view(np.int32)).to(dev)
+    d_res = torch.empty(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.hint_mean_len(hint)
+    try:
+        ctx.verify_dev(d_arena.data_ptr(), arena.nbytes, p_off, stride16, d_len.data_ptr(), n, ifc, d_res.data_ptr())
+        seeds = rng.integers(0, 65536, size=n).astype(np.uint16)
+        d_seeds = torch.from_numpy(seeds.view(np.int16)).to(dev)
+        d_sum = torch.empty(n, dtype=torch.int16, device=dev)
+        torch.cuda.synchronize()
+        ctx.csum_batch_dev(d_arena.data_ptr(), arena.nbytes, p_off, stride16, d_len.data_ptr(), d_seeds.data_ptr(), n, d_sum.data_ptr())
+        torch.cuda.synchronize()
+        got = d_res.cpu().numpy().view(unet_amd.RESULT_DTYPE)
+        exp = O.recv_batch(arena, off16, lens, ifc, stride16=stride16)
+        bad = np.nonzero(got != exp)[0]
+        assert bad.size == 0, ("verify_dev", tag, bad[:5], got[bad[:5]], exp[bad[:5]], lens[bad[:5]])
+        g = d_sum.cpu().numpy().view(np.uint16)
+        e = O.csum_batch(arena, off16, lens, seeds, stride16=stride16)
+        assert (g == e).all(), ("csum_batch_dev", tag, np.nonzero(g != e)[0][:5])
+        if mode == unet_amd.MODE_L3:
+            d_status = torch.empty(n, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            ctx.generate_dev(d_arena.data_ptr(), arena.nbytes, p_off, stride16, d_len.data_ptr(), n, d_status.data_ptr())
+            torch.cuda.synchronize()
+            ea, es = O.generate_batch(arena, off16, lens, stride16=stride16)
+            assert (d_status.cpu().numpy() == es).all(), ("generate_dev status", tag)
+            assert (d_arena.cpu().numpy() == ea).all(), ("generate_dev bytes", tag)
+    finally:
+        ctx.hint_mean_len(0)
+    return tag
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -160,6 +208,7 @@ def main():
         while time.time() - t0 < seconds:
             one_round(ctx, seed + rounds)
             tx_round(ctx, seed + rounds)
+            dev_round(ctx, seed + rounds)
             rounds += 1
             if time.time() - last > 30:
                 last = time.time()
