@@ -133,6 +133,11 @@ int unet_sync(unet_ctx* ctx);
  * wrong for an arena with gaps.  A caller that knows better says so here (0 = back to the estimate).  Only
  * speed depends on it, never results. */
 int unet_hint_mean_len(unet_ctx* ctx, uint32_t mean_len);
+/* The number of records one wavefront is given for a batch whose mean record length is `mean_len` bytes and whose
+ * longest record is `max_len` bytes (0 = not known, as for the *_dev entry points): 64, 48, 40, 32, 16, 8, 4, 2 or
+ * 1.  A pure function of its arguments that touches no GPU -- for logs, for sizing experiments with UNET_TILE, and
+ * so that the rule can be tested without a device.  (No counterpart in the reference, which has no batches.) */
+int unet_records_per_wave(uint32_t mean_len, uint32_t max_len);
 
 /* -------------------------------------------------- frame arena layout */
 /* A batch is `n` records in one byte arena.  Record i starts at byte 16*off16[i]

@@ -45,6 +45,22 @@ def test_missing_library_is_loud(tmp_path):
         unet_amd.load_library(str(tmp_path / "nope.so"))
 
 
+def test_records_per_wave_rule():
+    """The host's choice of records per wavefront, at every boundary of the rule (no GPU involved)."""
+    rpw = _ffi.records_per_wave
+    # shortest records: 64 to a wave when none is known to be longer than 64 bytes, or -- lengths unseen -- by the mean
+    assert [rpw(0), rpw(64), rpw(65), rpw(1024)] == [64, 64, 32, 32]
+    assert [rpw(40, 64), rpw(40, 65), rpw(40, 80), rpw(40, 81), rpw(40, 96), rpw(40, 97), rpw(40, 1500)] == [64, 48, 48, 40, 40, 32, 32]
+    assert rpw(64, 64) == 64 and rpw(70, 96) == 40 and rpw(1024, 1024) == 32 and rpw(600, 9000) == 32
+    # long records: sixteen up to 1536 bytes, then about 16 KiB per wave, and eight of the very longest
+    assert [rpw(1025), rpw(1500, 1500), rpw(1536), rpw(1537)] == [16, 16, 16, 8]
+    assert [rpw(2048), rpw(2049), rpw(4096), rpw(4097), rpw(8192), rpw(8193), rpw(16384), rpw(49151), rpw(49152), rpw(65535)] == [8, 4, 4, 2, 2, 1, 1, 1, 8, 8]
+    # the longest record does not matter above 1 KiB of mean
+    assert rpw(3000, 65535) == rpw(3000) == 4
+    for mean in range(0, 65536, 7):
+        assert rpw(mean) in (64, 32, 16, 8, 4, 2, 1)
+
+
 def test_pack_arena_layout():
     frames = [b"", b"a", b"b" * 16, b"c" * 17, b"d" * 1500]
     arena, off16, lens = unet_amd.pack_arena(frames)

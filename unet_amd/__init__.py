@@ -18,6 +18,7 @@ from ._ffi import (  # noqa: F401
     synth_flow_hash,
     synth_host,
     synth_layout,
+    records_per_wave,
     synth_len,
 )
 

@@ -273,8 +273,6 @@ int check_batch(unet_ctx* ctx, const void* arena, const void* off16, u32 stride1
 }
 // the kernels may touch the arena's first 16 bytes even when every record is empty
 inline bool arena_too_small(u64 arena_bytes) { return arena_bytes < 16; }
-// Records per wave: long records want short tiles (fine-grained tail of the launch), short records
-// want many lanes busy in the lane-parallel phase.
 // Records per wave.  16 down to 1 for long records (about 16 KiB per wave), 32 up to 1 KiB, and 64-record tiles
 // for batches of the shortest records only (at most 64 bytes): their kernel stages a tile's byte range in LDS when
 // it fits 4 KiB and reads any other tile with plain per-lane loops (correct for every length, slow for long
@@ -484,6 +482,8 @@ int unet_hint_mean_len(unet_ctx* c, uint32_t mean_len) {
     c->mean_len_hint = mean_len;
     return UNET_OK;
 }
+
+int unet_records_per_wave(uint32_t mean_len, uint32_t max_len) { return tile_for(mean_len, max_len != 0, max_len); }
 
 int unet_device_count(void) {
     int n = 0;
