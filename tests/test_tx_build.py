@@ -193,6 +193,32 @@ def test_tx_build_matches_oracle(offload, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [unet_amd.MODE_L3, unet_amd.MODE_L2])
+def test_tx_build_every_row_count_of_long_payloads(offload, mode):
+    """Payloads past their first two rows are copied in rows of 64 chunks, four rows to a step: every number of
+    rows from 0 to 13 with the last one holding 1, 2, 33, 63 or 64 chunks and ending on or off a 16-byte boundary."""
+    rng = np.random.default_rng(29 + mode)
+    ifc = unet_amd.Iface("192.0.2.2", "255.255.255.0", mac=bytes.fromhex("02aabbccddee"), mode=mode)
+    lens = []
+    for first_two in (125, 126):  # chunks of payload in rows 0/1 (Ethernet, raw IP output)
+        for rows in range(0, 14):
+            for last_row in (1, 2, 33, 63, 64):
+                chunks = first_two + 64 * rows + last_row
+                lens += [16 * chunks - d for d in (0, 1, 15)]
+    lens = [l for l in lens if l <= 65507] + list(range(1990, 12400, 97)) + [65507, 65493, 30000]
+    desc, payloads = make_batch(rng, lens, ifc)
+    arena, off16, plen = unet_amd.pack_arena(payloads, pad_byte=0x77)
+    ooff, obytes = tx_out_layout(plen, mode)
+    exp, exp_len, exp_status = O.tx_build_batch(arena, off16, plen, desc, ifc, ooff, obytes)
+    got, got_len, got_status = _gpu_build(offload, arena, off16, plen, desc, ifc, ooff, obytes)
+    assert (got_status == exp_status).all() and (got_status == 0).all() and (got_len == exp_len).all()
+    m = _valid_mask(obytes, ooff, exp_len)
+    bad = np.flatnonzero(got[:obytes][m] != exp[m])
+    assert bad.size == 0, (bad[:4], len(lens))
+    assert (got[:obytes][~m] == 0).all() and (got[obytes:] == 0xAB).all()
+
+
+@pytest.mark.gpu
 def test_tx_build_fixed_stride_and_status(offload):
     rng = np.random.default_rng(3)
     ifc = unet_amd.Iface()

@@ -58,6 +58,9 @@ struct Batch {
 #ifndef UNET_TX_MID_PATH
 #define UNET_TX_MID_PATH 1    // k_tx_build: lane groups for packets of up to 64 chunks
 #endif
+#ifndef UNET_TX_BURST
+#define UNET_TX_BURST 1       // k_tx_build: rows 2.. of a long payload requested four at a time (0: one at a time, in rotation)
+#endif
 #ifndef UNET_TX_G4
 #define UNET_TX_G4 1          // k_tx_build: groups of 4 lanes for packets of up to 16 chunks
 #endif
@@ -1179,6 +1182,41 @@ __device__ __forceinline__ void tx_build_one(const TxRows& cur, u32 lane, u32 fr
             if ((K) + lane + SH < nout) tx_store(splice<R>(X, h_), pout + (K) + lane + SH);       \
         }
         u32x4 ra, rb, rc, rd;
+#if UNET_TX_BURST
+        // four rows requested together with the first chunk of the row after them (one address for the whole wave),
+        // then spliced and stored
+        {
+            const u32x4 pk = tm.apply(zero_unless(ld_stream(cur.p + min(k, last)), k < nin), k);
+            fx = rdlane(pk.x, 0);
+            fy = rdlane(pk.y, 0);
+        }
+#pragma nounroll
+        for (; k + 4u * kWave <= kend; k += 4u * kWave) {
+            const u32 kn = k + 4u * kWave;
+            { UNET_TX_ROW(ra, k); }
+            { UNET_TX_ROW(rb, k + kWave); }
+            { UNET_TX_ROW(rc, k + 2u * kWave); }
+            { UNET_TX_ROW(rd, k + 3u * kWave); }
+            const u32x4 pk = tm.apply(zero_unless(ld_stream(cur.p + min(kn, last)), kn < nin), kn);
+            UNET_TX_EMIT(ra, rb, k)
+            UNET_TX_EMIT(rb, rc, k + kWave)
+            UNET_TX_EMIT(rc, rd, k + 2u * kWave)
+            UNET_TX_EMIT(rd, pk, k + 3u * kWave)
+        }
+        if (k < kend) {  // fewer than 256 chunks are left: only the rows that hold some of them are requested
+            const bool has_b = k + kWave < kend, has_c = k + 2u * kWave < kend, has_d = k + 3u * kWave < kend;
+            const u32x4 zero = {0, 0, 0, 0};
+            rb = rc = rd = zero;
+            { UNET_TX_ROW(ra, k); }
+            if (has_b) { UNET_TX_ROW(rb, k + kWave); }
+            if (has_c) { UNET_TX_ROW(rc, k + 2u * kWave); }
+            if (has_d) { UNET_TX_ROW(rd, k + 3u * kWave); }
+            UNET_TX_EMIT(ra, rb, k)
+            if (has_b) UNET_TX_EMIT(rb, rc, k + kWave)
+            if (has_c) UNET_TX_EMIT(rc, rd, k + 2u * kWave)
+            if (has_d) UNET_TX_EMIT(rd, zero, k + 3u * kWave)
+        }
+#else
         { UNET_TX_ROW(ra, k); }
         { UNET_TX_ROW(rb, k + kWave); }
         { UNET_TX_ROW(rc, k + 2u * kWave); }
@@ -1200,6 +1238,7 @@ __device__ __forceinline__ void tx_build_one(const TxRows& cur, u32 lane, u32 fr
             k += 4u * kWave;
             if (k >= kend) break;
         }
+#endif
 #undef UNET_TX_ROW
 #undef UNET_TX_EMIT
     }

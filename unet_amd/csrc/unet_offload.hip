@@ -185,7 +185,6 @@ struct unet_ctx {
     int tile_override = 0;        // UNET_TILE, read once at unet_open
     int tx_tile_override = 0;     // UNET_TX_TILE (4, 8, 16, 32, 64), read once at unet_open
     int tile_once = 0;            // records per wave for the launch a host-pointer entry point is about to make
-    int tx_tile_once = 0;         // packets per wave for the next unet_tx_build_dev call only (set by unet_tx_build)
     bool hdr_plain = false;       // UNET_HDR_PLAIN, read once at unet_open
     u32 mean_len_hint = 0;        // unet_hint_mean_len
     bool len_known = false;       // set by the host-pointer entry points around their *_dev call
@@ -322,13 +321,15 @@ inline u64 pick_mean(const unet_ctx* c, u64 arena_bytes, u32 stride16, u32 n) {
     return arena_bytes / n;
 }
 // Packets per wave of k_tx_build for payloads that take a whole wave each (above 1 KiB): fewer than sixteen, for the
-// reason given in tile_for -- measured (TB/s, 16 / 8 / 4 per wave): 1472-byte payloads 5.11 / 5.36 / 5.23, 2000 B
-// 4.68 / 5.02 / 5.35, 4000 B 4.92 / 5.16 / 5.58, 8972 B 4.50 / 4.56 / 4.68, 65507 B 5.03 / 4.54 / 4.72.  Ethernet
-// output has no 4-packet instantiation.
-inline int tx_tile_long(u64 mean_payload, int mode) {
-    if (mean_payload >= 32768) return 16;
-    if (mode == UNET_MODE_L2) return 8;
-    return mean_payload < 1800 ? 8 : 4;
+// reason given in tile_for, down to one from 8 KB up.  Measured, TB/s at 8 / 4 / 2 / 1 per wave, raw IP output:
+// 1472-byte payloads 5.36 / 5.29 / 4.60 / 3.13, 3000 B 4.99 / 5.14 / 5.03 / 4.16, 4000 B 5.23 / 5.60 / 5.57 / 4.90,
+// 6000 B 4.84 / 5.04 / 5.29 / 5.17, 8972 B 4.65 / 4.78 / 5.18 / 5.29, 20000 B 4.85 / 5.01 / 5.24 / 5.46, 65507 B
+// 4.73 / 4.84 / 4.85 / 5.01; Ethernet output likewise (8972 B: 5.01 / 5.16 / 5.50 / 5.59).  Counts below the smallest
+// instantiation of the kernel (4, Ethernet 8) run that instantiation with part of its lanes.
+inline int tx_tile_long(u64 mean_payload) {
+    if (mean_payload < 2500) return 8;
+    if (mean_payload < 5000) return 4;
+    return mean_payload < 8000 ? 2 : 1;
 }
 
 inline hipStream_t pick(unet_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->s_comp; }
@@ -548,7 +549,7 @@ int unet_open(int device_id, unet_ctx** out_ctx) {
     if (const char* z = getenv("UNET_ZERO_COPY_BYTES")) c->zero_copy_bytes = strtoull(z, nullptr, 10);
     if (const char* t = getenv("UNET_TX_TILE")) {
         const int v = atoi(t);
-        c->tx_tile_override = v <= 4 ? 4 : (v <= 8 ? 8 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)));
+        c->tx_tile_override = v <= 1 ? 1 : (v <= 2 ? 2 : (v <= 4 ? 4 : (v <= 8 ? 8 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)))));
     }
     int rc = static_scratch_of(device_id, &c->scratch_dev);
     if (rc) {
@@ -1078,21 +1079,20 @@ int unet_tx_build_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload_aren
     Batch b{d_payload_arena, payload_arena_bytes, d_payload_off16, payload_stride16, d_payload_len, n};
     const IfaceDev ifc = to_dev(iface);
 #define UNET_TX_LAUNCH(M, T)                                                                                             \
-    hipLaunchKernelGGL((k_tx_build<M, T>), dim3(tiles_grid(n, T)), dim3(kBlock), 0, pick(ctx, stream), b, (const TxDesc*)d_desc, ifc, \
+    hipLaunchKernelGGL((k_tx_build<M, T>), dim3(tiles_grid(n, b.tile_n)), dim3(kBlock), 0, pick(ctx, stream), b, (const TxDesc*)d_desc, ifc, \
                        d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status)
     int tile = pick_tile(ctx, payload_arena_bytes, payload_stride16, n);
     if (tile > 32 && tile < 64) tile = 32;  // (the in-between sizes exist for the receive-side kernels only)
-    if (tile <= 16) tile = tx_tile_long(pick_mean(ctx, payload_arena_bytes, payload_stride16, n), iface->mode);
-    if (ctx->tx_tile_once) tile = ctx->tx_tile_once;
-    ctx->tx_tile_once = 0;
+    if (tile <= 16) tile = tx_tile_long(pick_mean(ctx, payload_arena_bytes, payload_stride16, n));
     if (ctx->tx_tile_override) tile = ctx->tx_tile_override;
+    b.tile_n = (u32)tile;  // fewer packets per wave than the smallest instantiation: that kernel, part of its lanes
     if (iface->mode == UNET_MODE_L2) {
-        if (tile == 8) UNET_TX_LAUNCH(MODE_L2, 8);
+        if (tile <= 8) UNET_TX_LAUNCH(MODE_L2, 8);
         else if (tile == 16) UNET_TX_LAUNCH(MODE_L2, 16);
         else if (tile == 32) UNET_TX_LAUNCH(MODE_L2, 32);
         else UNET_TX_LAUNCH(MODE_L2, 64);
     } else {
-        if (tile == 4) UNET_TX_LAUNCH(MODE_L3, 4);
+        if (tile <= 4) UNET_TX_LAUNCH(MODE_L3, 4);
         else if (tile == 8) UNET_TX_LAUNCH(MODE_L3, 8);
         else if (tile == 16) UNET_TX_LAUNCH(MODE_L3, 16);
         else if (tile == 32) UNET_TX_LAUNCH(MODE_L3, 32);
@@ -1168,9 +1168,6 @@ int unet_tx_build(unet_ctx* c, const uint8_t* payload_arena, uint64_t payload_ar
                 dout = (uint8_t*)c->d_tx.p;
             }
             LenScope hint(c, (u32)(im.sum_len / n), im.max_len);
-            // payloads that take a whole wave each, read across the link: eight per wave rather than sixteen, so that
-            // more waves pull on it
-            if (in_place && im.sum_len / n > 1024u) c->tx_tile_once = 8;
             rc = unet_tx_build_dev(c, nullptr, di + in_arena, im.used, payload_off16 ? (const uint32_t*)(di + in_off) : nullptr, payload_stride16,
                                    (const uint32_t*)di, (const unet_tx_desc*)(di + in_desc), n, iface, dout + o_arena, need,
                                    (const uint32_t*)(di + in_ooff), (uint32_t*)(dout + o_len), dout + o_st);
