@@ -11,7 +11,7 @@ import torch
 import unet_amd
 from unet_amd._ffi import TX_DESC_DTYPE, tx_frame_len
 
-sizes = [int(x) for x in sys.argv[1:]] or [18, 64, 128, 256, 548, 1000, 1472, 4000, 8972, 65507]
+sizes = [int(x) for x in sys.argv[1:]] or [18, 64, 128, 256, 548, 1000, 1472, 2000, 3000, 4000, 6000, 8972, 20000, 65507]
 ctx = unet_amd.Offload(0)
 st = torch.cuda.Stream()
 torch.cuda.set_stream(st)
