@@ -183,7 +183,7 @@ struct unet_ctx {
     DevBuf d_arena, d_off, d_len, d_out, d_aux, d_tx, d_tx_tab, d_tcp;
     CopyPool* pool = nullptr;
     int tile_override = 0;        // UNET_TILE, read once at unet_open
-    int tx_tile_override = 0;     // UNET_TX_TILE (4, 8, 16, 32, 64), read once at unet_open
+    int tx_tile_override = 0;     // UNET_TX_TILE (1, 2, 4, 8, 16, 32, 64), read once at unet_open
     int tile_once = 0;            // records per wave for the launch a host-pointer entry point is about to make
     bool hdr_plain = false;       // UNET_HDR_PLAIN, read once at unet_open
     u32 mean_len_hint = 0;        // unet_hint_mean_len
