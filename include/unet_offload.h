@@ -138,6 +138,8 @@ int unet_hint_mean_len(unet_ctx* ctx, uint32_t mean_len);
  * 1.  A pure function of its arguments that touches no GPU -- for logs, for sizing experiments with UNET_TILE, and
  * so that the rule can be tested without a device.  (No counterpart in the reference, which has no batches.) */
 int unet_records_per_wave(uint32_t mean_len, uint32_t max_len);
+/* The same for unet_tx_build*: packets per wavefront by mean payload length (64, 32, 16, 8, 4, 2 or 1). */
+int unet_tx_packets_per_wave(uint32_t mean_payload_len);
 
 /* -------------------------------------------------- frame arena layout */
 /* A batch is `n` records in one byte arena.  Record i starts at byte 16*off16[i]

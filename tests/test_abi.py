@@ -61,6 +61,12 @@ def test_records_per_wave_rule():
         assert rpw(mean) in (64, 32, 16, 8, 4, 2, 1)
 
 
+def test_tx_packets_per_wave_rule():
+    tpw = _ffi.tx_packets_per_wave
+    assert [tpw(0), tpw(18), tpw(112), tpw(113), tpw(599), tpw(600), tpw(1024), tpw(1025)] == [64, 64, 64, 32, 32, 16, 16, 8]
+    assert [tpw(1472), tpw(2499), tpw(2500), tpw(4999), tpw(5000), tpw(7999), tpw(8000), tpw(8972), tpw(65507)] == [8, 8, 4, 4, 2, 2, 1, 1, 1]
+
+
 def test_pack_arena_layout():
     frames = [b"", b"a", b"b" * 16, b"c" * 17, b"d" * 1500]
     arena, off16, lens = unet_amd.pack_arena(frames)

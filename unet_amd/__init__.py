@@ -20,6 +20,7 @@ from ._ffi import (  # noqa: F401
     synth_layout,
     records_per_wave,
     synth_len,
+    tx_packets_per_wave,
 )
 
 MODE_L3 = 0

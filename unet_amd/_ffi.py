@@ -157,6 +157,7 @@ _SIGS = {
     "unet_verify_static": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
     "unet_hint_mean_len": (C.c_int, [_vp, C.c_uint32]),
     "unet_records_per_wave": (C.c_int, [C.c_uint32, C.c_uint32]),
+    "unet_tx_packets_per_wave": (C.c_int, [C.c_uint32]),
     "unet_generate_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, _u8p]),
     "unet_checksum_fields_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, _vp, _u8p]),
     "unet_generate": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, _u8p]),
@@ -252,6 +253,11 @@ def _aligned_u8(nbytes: int) -> np.ndarray:
 def records_per_wave(mean_len: int, max_len: int = 0) -> int:
     """Records one wavefront is given for a batch of this mean (and, if known, longest) record length."""
     return int(load_library().unet_records_per_wave(int(mean_len), int(max_len)))
+
+
+def tx_packets_per_wave(mean_payload_len: int) -> int:
+    """Packets one wavefront builds for a batch of this mean payload length."""
+    return int(load_library().unet_tx_packets_per_wave(int(mean_payload_len)))
 
 
 def synth_len(kind: int, seed: int, idx: int) -> int:

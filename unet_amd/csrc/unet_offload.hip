@@ -332,6 +332,16 @@ inline int tx_tile_long(u64 mean_payload) {
     return mean_payload < 8000 ? 2 : 1;
 }
 
+// Packets per wave of k_tx_build by mean payload length.  Up to about 112 bytes (one lane or four to a packet) 64 --
+// 100 B 4.62 -> 5.01 TB/s against 32 (raw IP), 4.27 -> 4.54 (Ethernet); 128 B the same either way, 200 B better with 32.
+// From 600 bytes (16 lanes to a packet, four packets to a step) sixteen -- 640 B 5.39 -> 5.55 TB/s, 800 B 5.36 -> 5.57,
+// 960 B 5.12 -> 5.56, 1024 B 5.12 -> 5.32; below that 32 is as good or better.  Above 1 KiB see tx_tile_long.
+inline int tx_tile_for(u64 mean_payload) {
+    if (mean_payload > 1024) return tx_tile_long(mean_payload);
+    if (mean_payload >= 600) return 16;
+    return mean_payload <= 112 ? 64 : 32;
+}
+
 inline hipStream_t pick(unet_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->s_comp; }
 inline u32 tiles_grid(u32 n, u32 tile) {
     const u32 tiles = (n + tile - 1) / tile;
@@ -485,6 +495,7 @@ int unet_hint_mean_len(unet_ctx* c, uint32_t mean_len) {
 }
 
 int unet_records_per_wave(uint32_t mean_len, uint32_t max_len) { return tile_for(mean_len, max_len != 0, max_len); }
+int unet_tx_packets_per_wave(uint32_t mean_payload_len) { return tx_tile_for(mean_payload_len); }
 
 int unet_device_count(void) {
     int n = 0;
@@ -1081,16 +1092,7 @@ int unet_tx_build_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload_aren
 #define UNET_TX_LAUNCH(M, T)                                                                                             \
     hipLaunchKernelGGL((k_tx_build<M, T>), dim3(tiles_grid(n, b.tile_n)), dim3(kBlock), 0, pick(ctx, stream), b, (const TxDesc*)d_desc, ifc, \
                        d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status)
-    int tile = pick_tile(ctx, payload_arena_bytes, payload_stride16, n);
-    if (tile > 32 && tile < 64) tile = 32;  // (the in-between sizes exist for the receive-side kernels only)
-    const u64 mean_payload = pick_mean(ctx, payload_arena_bytes, payload_stride16, n);
-    if (tile <= 16) tile = tx_tile_long(mean_payload);
-    // 600..1024-byte payloads (16 lanes to a packet, four packets to a step): sixteen to a wave rather than 32 -- 640 B
-    // 5.39 -> 5.55 TB/s, 800 B 5.36 -> 5.57, 960 B 5.12 -> 5.56, 1024 B 5.12 -> 5.32; below that 32 is as good or better
-    else if (tile == 32 && mean_payload >= 600 && !ctx->tile_override) tile = 16;
-    // payloads of up to about 112 bytes (one lane or four to a packet): 64 to a wave -- 100 B 4.62 -> 5.01 TB/s (raw IP),
-    // 4.27 -> 4.54 (Ethernet); 128 B the same either way, 200 B better with 32
-    else if (tile == 32 && mean_payload <= 112 && !ctx->tile_override) tile = 64;
+    int tile = tx_tile_for(pick_mean(ctx, payload_arena_bytes, payload_stride16, n));
     if (ctx->tx_tile_override) tile = ctx->tx_tile_override;
     b.tile_n = (u32)tile;  // fewer packets per wave than the smallest instantiation: that kernel, part of its lanes
     if (iface->mode == UNET_MODE_L2) {
