@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Prints the by-batch-size tables of DESIGN.md from profiles/<tag>/batch_size_sweep.jsonl (markdown).
-usage: tools/design_tables.py <tag> [--write]    --write replaces the two tables in DESIGN.md in place"""
+"""Prints the by-batch-size latency tables (markdown) from profiles/<tag>/batch_size_sweep.jsonl.
+usage: tools/design_tables.py <tag> [--write]    --write replaces the two tables in the design document in place"""
 import json
 import os
 import sys

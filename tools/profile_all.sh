@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything the measurement section of DESIGN.md cites, produced in one go on the GPU box, under
+# Every measurement the design document cites, produced in one go on the GPU box, under
 # gpurun_out/profile_<tag>/ (tools/collect_profiles.py <tag> then copies it to profiles/<tag>/):
 #   per workload: bench JSON under rocprofv3 --kernel-trace --stats, and the two HBM-traffic counter passes
 #   bench JSONs without a profiler for the remaining workloads, the emulated ranks of an 8-GPU job
