@@ -67,6 +67,23 @@ def test_tx_packets_per_wave_rule():
     assert [tpw(1472), tpw(2499), tpw(2500), tpw(4999), tpw(5000), tpw(7999), tpw(8000), tpw(8972), tpw(65507)] == [8, 8, 4, 4, 2, 2, 1, 1, 1]
 
 
+def test_tx_layout_aligned_matches_python_and_rejects_bad_alignment():
+    lib = unet_amd.load_library()
+    rng = np.random.default_rng(8)
+    plen = rng.integers(0, 9000, size=500).astype(np.uint32)
+    for mode in (0, 1):
+        for align16 in (1, 2, 8, 64):
+            off = np.zeros(500, dtype=np.uint32)
+            need = ctypes.c_uint64(0)
+            rc = lib.unet_tx_layout_aligned(_ffi._np_ptr(plen), 500, mode, align16, _ffi._np_ptr(off), ctypes.byref(need))
+            assert rc == 0
+            eoff, ebytes = _ffi.tx_out_layout(plen, mode, align16)
+            assert (off == eoff).all() and need.value == ebytes and (off % align16 == 0).all()
+    need = ctypes.c_uint64(0)
+    for bad in (0, 3, 128):
+        assert lib.unet_tx_layout_aligned(_ffi._np_ptr(plen), 500, 0, bad, None, ctypes.byref(need)) == -1
+
+
 def test_pack_arena_layout():
     frames = [b"", b"a", b"b" * 16, b"c" * 17, b"d" * 1500]
     arena, off16, lens = unet_amd.pack_arena(frames)

@@ -219,6 +219,31 @@ def test_tx_build_every_row_count_of_long_payloads(offload, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [unet_amd.MODE_L3, unet_amd.MODE_L2])
+def test_tx_build_into_a_line_aligned_layout(offload, mode):
+    """Packets placed on 128-byte lines (unet_tx_layout_aligned, align16 = 8): the same bytes as the oracle's, and the
+    slots' spare chunks are left as they were."""
+    rng = np.random.default_rng(41 + mode)
+    ifc = unet_amd.Iface("192.0.2.2", "255.255.255.0", mac=bytes.fromhex("02aabbccddee"), mode=mode)
+    lens = LENS + [int(x) for x in rng.integers(0, 3000, size=1500)] + [4000, 6000, 20000, 65507]
+    desc, payloads = make_batch(rng, lens, ifc)
+    arena, off16, plen = unet_amd.pack_arena(payloads, pad_byte=0x77)
+    ooff, obytes = tx_out_layout(plen, mode, align16=8)
+    assert (ooff % 8 == 0).all()
+    exp, exp_len, exp_status = O.tx_build_batch(arena, off16, plen, desc, ifc, ooff, obytes)
+    got, got_len, got_status = _gpu_build(offload, arena, off16, plen, desc, ifc, ooff, obytes)
+    assert (got_status == exp_status).all() and (got_status == 0).all() and (got_len == exp_len).all()
+    for o, l in zip(ooff, exp_len):
+        a, b = 16 * int(o), 16 * int(o) + int(l)
+        assert (got[a:b] == exp[a:b]).all(), (int(o), int(l))
+    # chunks of a slot that hold no packet bytes keep the buffer's fill (0xAB); the packet's own last chunk is zero-padded
+    slots = (ooff.astype(np.int64) + (exp_len.astype(np.int64) + 15) // 16)
+    nxt = np.append(ooff[1:].astype(np.int64), obytes // 16)
+    for s0, s1 in zip(slots, nxt):
+        assert (got[16 * int(s0):16 * int(s1)] == 0xAB).all()
+
+
+@pytest.mark.gpu
 def test_tx_build_fixed_stride_and_status(offload):
     rng = np.random.default_rng(3)
     ifc = unet_amd.Iface()

@@ -24,6 +24,8 @@ for mode in (0, 1):
         n = min(total // (slots * 16), 1 << 24)
         flen = int(tx_frame_len(L, mode))
         oslots = (flen + 15) // 16
+        if os.environ.get("TX_SWEEP_LINE_ALIGNED"):
+            oslots = (oslots + 7) // 8 * 8  # every packet starts on a 128-byte line
         desc = np.zeros(n, dtype=TX_DESC_DTYPE)
         desc["src"], desc["dst"], desc["proto"], desc["l4a"], desc["l4b"] = ifc.unicast, 0xC6336407, 17, 1234, 4321
         desc["ip_id"] = np.arange(n) & 0xFFFF

@@ -125,9 +125,10 @@ def tx_frame_len(payload_len, mode: int):
     return l3 if mode == 0 else 14 + np.maximum(l3, 60)
 
 
-def tx_out_layout(payload_len, mode: int):
-    """(out_off16, out_arena_bytes) for packing the built packets back to back on 16-byte boundaries."""
-    slots = (tx_frame_len(payload_len, mode) + 15) // 16
+def tx_out_layout(payload_len, mode: int, align16: int = 1):
+    """(out_off16, out_arena_bytes) for packing the built packets back to back on 16-byte boundaries, or on
+    multiples of align16 such slots (8 = 128-byte lines)."""
+    slots = ((tx_frame_len(payload_len, mode) + 15) // 16 + align16 - 1) // align16 * align16
     off16 = np.zeros(len(slots), dtype=np.int64)
     np.cumsum(slots[:-1], out=off16[1:])
     return off16.astype(np.uint32), int(max(16, 16 * int(slots.sum())))
@@ -164,6 +165,7 @@ _SIGS = {
     "unet_tx_build_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, _vp, C.c_uint32, C.POINTER(_IfaceC), _u8p,
                                     C.c_uint64, _u32p, _u32p, _u8p]),
     "unet_tx_layout": (C.c_int, [_u32p, C.c_uint32, C.c_int, _u32p, C.POINTER(C.c_uint64)]),
+    "unet_tx_layout_aligned": (C.c_int, [_u32p, C.c_uint32, C.c_int, C.c_uint32, _u32p, C.POINTER(C.c_uint64)]),
     "unet_tx_build": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, _vp, C.c_uint32, C.POINTER(_IfaceC), _u8p, C.c_uint64,
                                 _u32p, _u32p, _u8p]),
     "unet_count_verdicts_dev": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _u64p]),

@@ -1112,9 +1112,11 @@ int unet_tx_build_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload_aren
     return UNET_OK;
 }
 
-int unet_tx_layout(const uint32_t* payload_len, uint32_t n, int mode, uint32_t* out_off16, uint64_t* out_arena_bytes) {
+int unet_tx_layout_aligned(const uint32_t* payload_len, uint32_t n, int mode, uint32_t align16, uint32_t* out_off16,
+                           uint64_t* out_arena_bytes) {
     if ((n && !payload_len) || !out_arena_bytes) return fail(UNET_E_INVAL, "null argument");
     if (mode != UNET_MODE_L3 && mode != UNET_MODE_L2) return fail(UNET_E_INVAL, "bad mode %d", mode);
+    if (align16 == 0 || align16 > 64 || (align16 & (align16 - 1u)) != 0) return fail(UNET_E_INVAL, "align16 must be 1, 2, 4 ... 64, got %u", align16);
     u64 slot = 0;
     for (u32 i = 0; i < n; i++) {
         if (payload_len[i] > kMaxLen) return fail(UNET_E_RANGE, "payload %u: length %u > 65535", i, payload_len[i]);
@@ -1122,10 +1124,14 @@ int unet_tx_layout(const uint32_t* payload_len, uint32_t n, int mode, uint32_t* 
         const u64 frame = mode == UNET_MODE_L2 ? 14ull + (l3 < 60 ? 60 : l3) : l3;
         if (slot > 0xffffffffull) return fail(UNET_E_RANGE, "output needs more than 2^32 16-byte slots");
         if (out_off16) out_off16[i] = (u32)slot;
-        slot += (frame + 15u) >> 4;
+        slot += (((frame + 15u) >> 4) + align16 - 1u) & ~(u64)(align16 - 1u);
     }
     *out_arena_bytes = slot ? slot * 16u : 16u;
     return UNET_OK;
+}
+
+int unet_tx_layout(const uint32_t* payload_len, uint32_t n, int mode, uint32_t* out_off16, uint64_t* out_arena_bytes) {
+    return unet_tx_layout_aligned(payload_len, n, mode, 1, out_off16, out_arena_bytes);
 }
 
 int unet_tx_build(unet_ctx* c, const uint8_t* payload_arena, uint64_t payload_arena_bytes, const uint32_t* payload_off16,
