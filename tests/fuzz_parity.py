@@ -1,7 +1,8 @@
 """Randomised parity soak: batches with random length mixes, layouts, modes and contents through unet_verify (and its
 static and asynchronous forms), unet_ipv4_validate, unet_csum_batch, unet_generate and unet_tx_build, every result against the CPU oracle.  Not collected by pytest (it runs for as
 long as it is told to); tests/test_fuzz_short.py runs a few rounds of it.  dev_round sends a batch through the device-pointer entry
-points, where the library chooses records per wave from the arena size, the stride or a caller's hint instead of from the lengths.
+points, where the library chooses records per wave from the arena size, the stride or a caller's hint instead of from the lengths;
+tx_dev_round does the same for unet_tx_build_dev, into packed and into line-aligned output layouts.
 
 usage: python tests/fuzz_parity.py [seconds] [first seed]"""
 import os
@@ -199,6 +200,60 @@ def dev_round(ctx, seed):
     return tag
 
 
+def tx_dev_round(ctx, seed):
+    """unet_tx_build_dev on payloads already in device memory, packets packed or on 128-byte lines, with no length hint, a
+    true one or a wrong one; every packet byte against the oracle and every byte between packets untouched."""
+    import torch
+    from unet_amd._ffi import TX_DESC_DTYPE, tx_out_layout
+    rng = np.random.default_rng(seed)
+    mode = unet_amd.MODE_L2 if rng.random() < 0.4 else unet_amd.MODE_L3
+    ifc = unet_amd.Iface("192.0.2.2", "255.255.255.0", mac=bytes.fromhex("02aabbccddee"), mode=mode)
+    n = int(rng.choice([1, 3, 4, 5, 16, 33, 64, 65, 300, 1500]))
+    lens = np.asarray(LENGTH_CLASSES[int(rng.integers(len(LENGTH_CLASSES)))](rng, n), dtype=np.int64)
+    frames = [rng.integers(0, 256, size=int(l), dtype=np.uint8).tobytes() for l in lens]
+    arena, off16, stride16, plen, how = layout(rng, frames)
+    desc = np.zeros(n, dtype=TX_DESC_DTYPE)
+    desc["src"] = np.where(rng.random(n) < 0.2, 0, ifc.unicast)
+    desc["dst"] = rng.integers(0, 2**32, size=n, dtype=np.uint64).astype(np.uint32)
+    desc["l4a"] = rng.integers(0, 65536, size=n)
+    desc["l4b"] = rng.integers(0, 65536, size=n)
+    desc["values"] = rng.integers(0, 2**32, size=n, dtype=np.uint64).astype(np.uint32)
+    desc["ip_id"] = rng.integers(0, 65536, size=n)
+    desc["proto"] = np.where(rng.random(n) < 0.3, 1, 17)
+    desc["dst_mac"] = rng.integers(0, 256, size=(n, 6), dtype=np.uint8)
+    align16 = int(rng.choice([1, 1, 8, 2]))
+    hint = int(rng.choice([0, 0, max(1, int(plen.mean())), 40, 700, 3000, 60000]))
+    ooff, obytes = tx_out_layout(plen, mode, align16)
+    tag = (seed, n, mode, how, int(plen.max()), round(float(plen.mean()), 1), align16, hint)
+    exp, exp_len, exp_status = O.tx_build_batch(arena, off16, plen, desc, ifc, ooff, obytes, pay_stride16=stride16)
+    dev = torch.device("cuda:0")
+    d_arena = torch.from_numpy(arena).to(dev)
+    d_off = None if off16 is None else torch.from_numpy(off16.view(np.int32)).to(dev)
+    d_len = torch.from_numpy(plen.view(np.int32)).to(dev)
+    d_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(dev)
+    d_ooff = torch.from_numpy(ooff.view(np.int32)).to(dev)
+    d_out = torch.full((obytes + 256,), 0xAB, dtype=torch.uint8, device=dev)
+    d_olen = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_st = torch.full((n,), 0xEE, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.hint_mean_len(hint)
+    try:
+        ctx.tx_build_dev(d_arena.data_ptr(), arena.nbytes, 0 if d_off is None else d_off.data_ptr(), stride16, d_len.data_ptr(),
+                         d_desc.data_ptr(), n, ifc, d_out.data_ptr(), obytes, d_ooff.data_ptr(), d_olen.data_ptr(), d_st.data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        ctx.hint_mean_len(0)
+    got, got_len, got_st = d_out.cpu().numpy(), d_olen.cpu().numpy().view(np.uint32), d_st.cpu().numpy()
+    assert (got_st == exp_status).all() and (got_len == exp_len).all(), ("tx_dev status", tag)
+    keep = np.ones(obytes + 256, dtype=bool)  # bytes no packet's chunks cover
+    for o, l in zip(ooff, exp_len):
+        a, b = int(o) * 16, int(o) * 16 + int(l)
+        assert (got[a:b] == exp[a:b]).all(), ("tx_dev bytes", tag, int(o), int(l))
+        keep[a:a + (int(l) + 15) // 16 * 16] = False
+    assert (got[keep] == 0xAB).all(), ("tx_dev wrote outside its packets", tag)
+    return tag
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -209,6 +264,7 @@ def main():
             one_round(ctx, seed + rounds)
             tx_round(ctx, seed + rounds)
             dev_round(ctx, seed + rounds)
+            tx_dev_round(ctx, seed + rounds)
             rounds += 1
             if time.time() - last > 30:
                 last = time.time()

@@ -3,7 +3,7 @@ unet_verify, unet_csum_batch, unet_generate and unet_tx_build, against the CPU o
 import pytest
 
 import unet_amd
-from fuzz_parity import dev_round, one_round, tx_round
+from fuzz_parity import dev_round, one_round, tx_dev_round, tx_round
 
 pytestmark = pytest.mark.gpu
 
@@ -13,3 +13,4 @@ def test_fuzz_rounds(offload):
         one_round(offload, seed)
         tx_round(offload, seed)
         dev_round(offload, seed)
+        tx_dev_round(offload, seed)
