@@ -17,7 +17,7 @@ Workloads (BASELINE.json configs):
 One "step" = one launch of the kernel over the rank's whole resident batch.  With N > 1 the global batch
 is N times larger and every rank takes the records whose 5-tuple flow hash % N is its rank (computed
 from the trace definition, before any record exists), so a flow stays on one GPU and nothing crosses
-GPUs on the data path; only the 32 per-verdict counters are all-reduced (RCCL) after the timed region.
+GPUs on the data path; only the per-verdict counters (UNET_V_COUNT u64) are all-reduced (RCCL) after the timed region.
 Rank 0 prints one JSON line.
 """
 import argparse
@@ -108,8 +108,12 @@ def self_launch(argv, gpus):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    return subprocess.call(cmd)
+           "--master-port", str(port), "--max-restarts", "0", os.path.abspath(__file__)] + list(argv)
+    # the launcher ends every rank when one of them fails and exits non-zero itself: that code is this job's
+    rc = subprocess.call(cmd)
+    if rc != 0:
+        print(f"bench.py: the {gpus}-rank job failed (launcher exit code {rc})", file=sys.stderr, flush=True)
+    return rc if rc else 0
 
 
 def cpu_baseline(kind, ifc, budget_s):
@@ -324,6 +328,11 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--all-on-gpu0", action="store_true", help="rehearsal on a one-GPU box: every rank uses cuda:0")
     ap.add_argument("--dry-run", action="store_true", help="start the ranks, rendezvous, print who is there, stop before any GPU call")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group (RCCL with --backend nccl) even with one rank, so that the barrier, the counter "
+                         "all-reduce and the size all-gather of the multi-GPU path run on a one-GPU box")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="with --dry-run: this rank exits with an error before the rendezvous")
+    ap.add_argument("--rendezvous-seconds", type=float, default=180.0, help="give up when the ranks have not all met after this long")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -334,10 +343,18 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if args.dry_run:
+        import datetime
+
         import torch.distributed as dist
+        if args.dry_run_fail_rank == rank:
+            raise SystemExit(f"rank {rank}: asked to fail before the rendezvous (--dry-run-fail-rank)")
         seen = [rank]
-        if world > 1:
-            dist.init_process_group("gloo")
+        if world > 1 or args.force_dist:
+            if "MASTER_ADDR" not in os.environ:
+                with socket.socket() as s:
+                    s.bind(("127.0.0.1", 0))
+                    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s.getsockname()[1]))
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=args.rendezvous_seconds), rank=rank, world_size=world)
             t = torch.zeros(world, dtype=torch.int64)
             t[rank] = rank + 1
             dist.all_reduce(t)
@@ -352,12 +369,20 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
+        import datetime
+
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:  # --force-dist without a launcher: a rendezvous of one
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s.getsockname()[1]))
+        # a rank that died before the rendezvous must not leave the others waiting for ever
+        limit = datetime.timedelta(seconds=args.rendezvous_seconds)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=limit, rank=rank, world_size=world)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=limit, rank=rank, world_size=world)
     shard_world, shard_rank = (args.emulate_world, args.emulate_rank) if args.emulate_world else (world, rank)
 
     kind, n_per_gpu, stride16 = WORKLOADS[args.workload]
@@ -588,7 +613,7 @@ def main():
                        "arena_bytes_rank0": b0.nbytes, "ext_tcp": ext_tcp, "batches_rotated": rotate,
                        "sharding": sharding, "shard_sizes": [s // rotate for s in all_sizes],
                        "shard_skew_max_over_mean": max(all_sizes) / (sum(all_sizes) / len(all_sizes)),
-                       "collectives": "none on the data path; 32 u64 verdict counters all-reduced (RCCL) after the timed region",
+                       "collectives": f"none on the data path; {unet_amd.V_COUNT} u64 verdict counters all-reduced (RCCL) after the timed region",
                        "inputs": "generated in HBM by unet_synth_indexed_dev before the timed region"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,

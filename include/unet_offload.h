@@ -30,7 +30,7 @@ extern "C" {
 #define UNET_E_HIP (-3)     /* a HIP runtime call failed; see unet_last_error() */
 #define UNET_E_NOMEM (-4)   /* host or device allocation failed */
 #define UNET_E_RANGE (-5)   /* a frame length > 65535 or an offset outside the arena */
-#define UNET_E_BUSY (-6)    /* unet_verify_async: UNET_ASYNC_DEPTH batches are already in flight */
+#define UNET_E_BUSY (-6)    /* unet_verify_async: UNET_ASYNC_DEPTH batches are already in flight; unet_verify_static: the GPU's static array is in use */
 
 /* ---------------------------------------------------------------- verdicts */
 /* One code per outcome of the reference's receive path; the FIRST failing check
@@ -213,8 +213,8 @@ int unet_wait(unet_ctx* ctx, unet_ticket ticket);
  * held by every GPU the library runs on until the process ends) and the call performs no hipMalloc / hipFree or
  * any other allocation.  Limits, checked with UNET_E_RANGE: at most UNET_STATIC_MAX_RECORDS records, all of them
  * ending inside the first UNET_STATIC_MAX_ARENA_BYTES bytes of the arena.  All contexts on one GPU share that
- * GPU's array, which keeps the previous call's bytes: calls that overlap on one GPU race with each other (one
- * caller thread per GPU, like every other host-pointer entry point of a context). */
+ * GPU's array, which keeps the previous call's bytes: a call that arrives while another one (of any context of this
+ * process on that GPU) is inside returns UNET_E_BUSY without touching anything. */
 #define UNET_STATIC_MAX_RECORDS 65536u
 #define UNET_STATIC_MAX_ARENA_BYTES (8u << 20)
 int unet_verify_static(unet_ctx* ctx, const uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16,
@@ -316,8 +316,11 @@ int unet_count_verdicts_dev(unet_ctx* ctx, void* stream, const unet_result* d_re
  * (unet_verify, unet_verify_async, unet_verify_static, unet_ipv4_validate) add the verdicts of every record they
  * judge, and unet_count_verdicts_dev adds to them when d_counts is NULL.  unet_counters waits for the context's
  * streams and copies them out (reset != 0: and zeroes them); unet_counters_sum adds up the counters of several
- * contexts, e.g. one per GPU of this process.  Across processes (one rank per GPU) the 256 bytes are summed by
- * the job's own collective: an RCCL all-reduce, or the launcher's. */
+ * contexts, e.g. one per GPU of this process.  Across processes (one rank per GPU) the UNET_V_COUNT * 8 = 320 bytes
+ * are summed by the job's own collective: an RCCL all-reduce, or the launcher's.  unet_counters waits for the
+ * context's OWN streams only: a unet_count_verdicts_dev(d_counts = NULL) enqueued on a caller's stream must have been
+ * synchronized by the caller before unet_counters is asked.  A counter array holds UNET_V_COUNT entries (40; it was
+ * 32 before DROP_TCP_OPTION = 32 existed): size d_counts with the constant, never with a literal. */
 int unet_counters(unet_ctx* ctx, uint64_t* out /* UNET_V_COUNT */, int reset);
 int unet_counters_sum(unet_ctx* const* ctxs, uint32_t n_ctx, uint64_t* out /* UNET_V_COUNT */, int reset);
 

@@ -399,3 +399,20 @@ pub fn calculate_checksum(data: &[u8], sum: u16) -> u16 {
 pub fn broadcast_of(unicast: u32, netmask: u32) -> u32 {
     (unicast & 0xffff_ff00) | (!netmask & 0xff)
 }
+
+#[cfg(test)]
+mod tests {
+    use super::*;
+
+    /// A batch whose only packet is empty: the arena holds no bytes at all, and the library must neither read
+    /// past it nor fail.  An empty buffer is shorter than an IPv4 header (the reference indexes out of bounds at
+    /// src/protocols/ipv4.rs:189-203; the offload's defined answer is DROP_L3_TRUNCATED).  Needs a GPU.
+    #[test]
+    #[ignore = "needs an MI355X"]
+    fn recv_batch_of_one_empty_packet() {
+        let mut off = Offload::open(0).expect("unet_open");
+        let res = off.recv_batch(&[&[][..]], 0xC000_0202, 0xC000_02ff).expect("recv_batch");
+        assert_eq!(res.len(), 1);
+        assert_eq!(res[0].verdict, sys::UNET_V_DROP_L3_TRUNCATED);
+    }
+}

@@ -46,6 +46,22 @@ def test_bench_under_the_drivers_launcher():
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["ranks"] == [0, 1]
 
 
+def test_one_rank_can_be_made_to_use_the_process_group():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--dry-run", "--force-dist"], capture_output=True, text=True, timeout=300,
+                       env=_clean_env())
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 1 and lines[0]["ranks"] == [0]
+
+
+def test_a_failing_rank_fails_the_job_without_a_hang():
+    # rank 1 dies before the rendezvous: the launcher must end rank 0 and the job must exit non-zero, soon
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--dry-run-fail-rank", "1", "--rendezvous-seconds", "60"],
+                       capture_output=True, text=True, timeout=240, env=_clean_env())
+    assert p.returncode != 0
+    assert "failed" in p.stderr and not _json_lines(p.stdout)
+
+
 def test_world_size_mismatch_is_refused():
     env = _clean_env()
     env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")

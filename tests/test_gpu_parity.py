@@ -532,6 +532,39 @@ def test_bad_arguments_are_rejected(offload):
     assert r["verdict"].tolist()[1:] == [0, 0] and r["verdict"][0] != 0
 
 
+def test_empty_records_in_an_arena_shorter_than_one_chunk(offload):
+    """Every image-based host-pointer entry point on a batch of empty records whose arena is shorter than 16 bytes
+    (the staging image is floored at one chunk; nothing past the caller's buffer may be read).  The buffer handed
+    over ends exactly at the end of a page-sized allocation's used part, and the answers must be the oracle's."""
+    lib = unet_amd.load_library()
+    ifc = unet_amd.Iface()
+    ic = ifc.c()
+    import ctypes as C
+    for n, arena_bytes in ((1, 0), (3, 0), (2, 8)):
+        backing = np.full(64, 0xA5, dtype=np.uint8)
+        base = backing.ctypes.data + (-backing.ctypes.data) % 16
+        lens = np.zeros(n, dtype=np.uint32)
+        off16 = np.zeros(n, dtype=np.uint32)
+        exp = O.recv_batch(np.zeros(16, dtype=np.uint8), off16, lens, ifc)
+        for entry in ("unet_verify", "unet_verify_static"):
+            out = np.zeros(n, dtype=unet_amd.RESULT_DTYPE)
+            rc = getattr(lib, entry)(offload.h, base, arena_bytes, off16.ctypes.data, 0, lens.ctypes.data, n, C.byref(ic), out.ctypes.data)
+            assert rc == 0, lib.unet_last_error()
+            assert np.array_equal(out, exp), entry
+        out = np.zeros(n, dtype=unet_amd.RESULT_DTYPE)
+        t = C.c_uint32(0)
+        assert lib.unet_verify_async(offload.h, base, arena_bytes, off16.ctypes.data, 0, lens.ctypes.data, n, C.byref(ic), out.ctypes.data, C.byref(t)) == 0
+        assert lib.unet_wait(offload.h, t.value) == 0
+        assert np.array_equal(out, exp)
+        ck = np.zeros(n, dtype=np.uint16)
+        assert lib.unet_csum_batch(offload.h, base, arena_bytes, off16.ctypes.data, 0, lens.ctypes.data, None, n, ck.ctypes.data) == 0
+        assert (ck == 0xFFFF).all()  # calculate_checksum(&[], 0), src/utils.rs:1-17
+        st = np.zeros(n, dtype=np.uint8)
+        assert lib.unet_generate(offload.h, base, arena_bytes, off16.ctypes.data, 0, lens.ctypes.data, n, st.ctypes.data) == 0
+        assert (st == int(Verdict.DROP_L3_TRUNCATED)).all()
+        assert (backing == 0xA5).all()
+
+
 # ------------------------------------------------------------------ full-size configurations (properties)
 
 def test_full_size_udp1500_batch_properties(offload):

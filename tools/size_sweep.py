@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Bandwidth of k_verify / k_csum as a function of record size: packed arenas of equal-length random
-records (about 4 GiB each), HIP-event timing on the launch stream."""
+records (about 4 GiB each), HIP-event timing on the launch stream.  UNET_SWEEP_L2=1 judges the records as
+Ethernet frames (MODE_L2) instead of L3 packets."""
 import json
 import os
 import sys
@@ -14,7 +15,8 @@ sizes = [int(x) for x in sys.argv[1:]] or [40, 64, 128, 144, 256, 576, 1024, 104
 ctx = unet_amd.Offload(0)
 st = torch.cuda.Stream()
 torch.cuda.set_stream(st)
-ifc = unet_amd.Iface(ext_tcp=True)
+l2 = bool(int(os.environ.get("UNET_SWEEP_L2", "0")))
+ifc = unet_amd.Iface(ext_tcp=True, mode=1 if l2 else 0)
 total = int(os.environ.get("UNET_SWEEP_TOTAL", 4 << 30))
 iters = int(os.environ.get("UNET_SWEEP_ITERS", 10))
 buf = torch.randint(0, 2**31 - 1, (total // 4 + 16,), dtype=torch.int32, device="cuda").view(torch.uint8)
@@ -25,7 +27,7 @@ for L in sizes:
     d_len = torch.full((n,), L, dtype=torch.int32, device="cuda")
     d_out = torch.zeros(n, dtype=torch.int32, device="cuda")
     nbytes = n * slots * 16
-    row = {"len": L, "records": n}
+    row = {"len": L, "records": n, "mode": "L2" if l2 else "L3"}
     for name in ("verify", "csum"):
         def run():
             if name == "verify":

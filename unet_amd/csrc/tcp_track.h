@@ -83,14 +83,17 @@ __global__ __launch_bounds__(kBlock) void k_tcp_keys(Batch b, const u32* __restr
     if (i >= b.n) return;
     idx[i] = i;
     u32 key = 1u << log2_slots;  // sorts behind every slot: not an accepted TCP segment
-    if (((results[i] >> 16) & 0xffu) == V_ACCEPT_TCP) {
+    const u32 flen = b.len[i];
+    const u64 slot = b.off16 ? (u64)b.off16[i] : (u64)i * b.stride16;
+    // d_results is only trusted as far as the tables allow: a verdict that claims a record the arena does not hold
+    // (results of another batch, a table changed in between) is treated as "not TCP"
+    const bool inside = flen <= kMaxLen && flen >= (MODE == MODE_L2 ? 54u : 40u) && slot * 16u + (((u64)flen + 15u) & ~15ull) <= b.arena_bytes;
+    const u32* w = reinterpret_cast<const u32*>(b.arena + (inside ? slot * 16u : 0ull));
+    auto f = [w](u32 k) { return w[k]; };
+    const u32 l3len = MODE == MODE_L2 ? flen - 14u : flen;
+    const u32 hl = inside ? (l3raw<MODE>(f, 0) & 0xfu) * 4u : 0u;
+    if (inside && ((results[i] >> 16) & 0xffu) == V_ACCEPT_TCP && hl >= 20u && hl + 20u <= l3len) {
         // the receive path has accepted it: the headers are complete and consistent
-        const u32 flen = b.len[i];
-        const u64 slot = b.off16 ? (u64)b.off16[i] : (u64)i * b.stride16;
-        const u32* w = reinterpret_cast<const u32*>(b.arena + slot * 16u);
-        auto f = [w](u32 k) { return w[k]; };
-        const u32 l3len = MODE == MODE_L2 ? flen - 14u : flen;
-        const u32 hl = (l3raw<MODE>(f, 0) & 0xfu) * 4u;
         TcpSeg s;
         s.src = bswap32(l3raw<MODE>(f, 12));
         s.dst = bswap32(l3raw<MODE>(f, 16));
@@ -100,7 +103,11 @@ __global__ __launch_bounds__(kBlock) void k_tcp_keys(Batch b, const u32* __restr
         s.seq = bswap32(l3raw<MODE>(f, hl + 4u));
         s.flags = (t3 >> 8) & 0xffu;
         const u32 doff = (t3 >> 4) & 0xfu;
-        const u32 payload = l3len - hl - doff * 4u;
+        // The segment is everything behind the IPv4 header in the buffer (src/protocols/ipv4.rs:415), the same rule
+        // the pseudo-header length of the verdict used: an Ethernet frame padded past its IPv4 total length fails that
+        // checksum and never gets here, so buffer length and total length agree for every accepted segment a sender
+        // built by that rule.
+        const u32 payload = hl + doff * 4u <= l3len ? l3len - hl - doff * 4u : 0u;
         s.consumed = payload + ((s.flags & kTcpSyn) ? 1u : 0u) + ((s.flags & kTcpFin) ? 1u : 0u);
         segs[i] = s;
         key = tcp_slot(flow_hash5(s.src, s.dst, 6u, sport, dport), log2_slots);

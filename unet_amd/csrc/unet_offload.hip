@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -168,6 +169,17 @@ int static_scratch_of(int dev, uint8_t** out) {
     *out = g_scratch_ptr[dev];
     return UNET_OK;
 }
+
+// One call at a time may use a device's copy of the array (all contexts of the process on that GPU share it).
+std::atomic<bool> g_scratch_busy[kMaxDevices];
+struct StaticInUse {
+    int dev;
+    bool mine;
+    explicit StaticInUse(int d) : dev(d), mine(!g_scratch_busy[d].exchange(true, std::memory_order_acquire)) {}
+    ~StaticInUse() {
+        if (mine) g_scratch_busy[dev].store(false, std::memory_order_release);
+    }
+};
 }  // namespace
 
 struct unet_ctx {
@@ -344,8 +356,16 @@ inline int tx_tile_for(u64 mean_payload) {
 
 inline hipStream_t pick(unet_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->s_comp; }
 inline u32 tiles_grid(u32 n, u32 tile) {
-    const u32 tiles = (n + tile - 1) / tile;
+    const u32 tiles = (u32)(((u64)n + tile - 1) / tile);
     return (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
+}
+// A launch may hold fewer than 2^32 threads: with `per_wave` records to a wave that bounds the batch.  (Only
+// reachable with one or two records per wave -- batches of jumbo records, or the UNET_TILE override.)
+inline int check_tiles(u32 n, u32 per_wave) {
+    if ((u64)tiles_grid(n, per_wave) * kBlock >= (1ull << 32))
+        return fail(UNET_E_RANGE, "%u records at %u per wavefront need 2^32 threads or more in one launch: split the batch (at most %llu records per call at this size)",
+                    n, per_wave, (unsigned long long)per_wave * ((1ull << 26) - 4u));
+    return UNET_OK;
 }
 
 // Shared body of the host-pointer batch calls: upload arena + tables, leave device views in `b`.
@@ -405,6 +425,7 @@ int launch_verify(hipStream_t s, const Batch& b_in, const unet_iface* iface, int
     Batch b = b_in;
     b.tile_n = (u32)records_per_wave;
     const u32 n = b.n;
+    if (int rc = check_tiles(n, (u32)records_per_wave)) return rc;
     const int tile = kernel_tile(records_per_wave);
 #define UNET_LAUNCH_VERIFY(M, T) \
     hipLaunchKernelGGL((k_verify<M, T>), dim3(tiles_grid(n, (u32)records_per_wave)), dim3(kBlock), 0, s, b, ifc, d_out)
@@ -436,6 +457,7 @@ struct LenScope {
 // One batch as a single staging image [len | off16 | arena bytes that hold records]: one host-to-device copy.
 struct Image {
     u64 at_off, at_arena, used, total, sum_len;
+    u64 src_bytes;  // the caller's arena_bytes: `used` may exceed it by the 16-byte floor when every record is empty
     u32 max_len;
 };
 
@@ -458,6 +480,7 @@ int plan_image(uint64_t arena_bytes, const uint32_t* off16, uint32_t stride16, c
     im->used = used;
     im->total = im->at_arena + used;
     im->sum_len = sum_len;
+    im->src_bytes = arena_bytes;
     im->max_len = longest;
     return UNET_OK;
 }
@@ -465,7 +488,11 @@ int plan_image(uint64_t arena_bytes, const uint32_t* off16, uint32_t stride16, c
 void fill_image(unet_ctx* c, uint8_t* pin, const Image& im, const uint8_t* arena, const uint32_t* off16, const uint32_t* len, uint32_t n) {
     memcpy(pin, len, (size_t)n * 4u);
     if (off16) memcpy(pin + im.at_off, off16, (size_t)n * 4u);
-    c->pool->copy(pin + im.at_arena, arena, im.used);
+    // `used` is at least 16 (the kernels may touch the arena's first chunk even when every record is empty), the
+    // caller's arena may be shorter than that: copy what exists, zero the rest
+    const u64 have = im.used < im.src_bytes ? im.used : im.src_bytes;
+    if (have) c->pool->copy(pin + im.at_arena, arena, have);
+    if (have < im.used) memset(pin + im.at_arena + have, 0, im.used - have);
 }
 
 Batch image_batch(const uint8_t* dev, const Image& im, bool has_off, uint32_t stride16, uint32_t n) {
@@ -621,6 +648,7 @@ int unet_csum_batch_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uin
     Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
     if (arena_too_small(arena_bytes)) return fail(UNET_E_INVAL, "arena must hold at least 16 bytes");
     b.tile_n = (u32)pick_tile(ctx, arena_bytes, stride16, n);
+    if ((rc = check_tiles(n, b.tile_n))) return rc;
     const dim3 grid(tiles_grid(n, b.tile_n));
     switch (kernel_tile((int)b.tile_n)) {
         case 16: hipLaunchKernelGGL(k_csum<16>, grid, dim3(kBlock), 0, pick(ctx, stream), b, d_seeds, d_out); break;
@@ -804,12 +832,11 @@ int unet_verify(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const u
     if (iface->mode != UNET_MODE_L3 && iface->mode != UNET_MODE_L2) return fail(UNET_E_INVAL, "bad iface mode %d", iface->mode);
     HIP_TRY(hipSetDevice(c->device));
     int rc;
-    if (arena_bytes + 2ull * n * 4u + 32u <= kStageBytes && (u64)n * 4u <= kStageBytes) {
+    if (arena_bytes + 2ull * n * 4u + 64u <= kStageBytes && (u64)n * 4u <= kStageBytes) {
         // small batch (a drained protocol queue): one staging image, one copy each way, everything on one stream
         Image im;
         if ((rc = plan_image(arena_bytes, off16, stride16, len, n, &im))) return rc;
         const u64 res_at = (im.total + 255u) & ~255ull;
-        if ((rc = ensure(c, c->d_arena, res_at + (u64)n * 4u))) return rc;
         HIP_TRY(hipEventSynchronize(c->pinned_free[0]));
         HIP_TRY(hipEventSynchronize(c->pinned_free[1]));
         fill_image(c, (uint8_t*)c->pinned[0], im, arena, off16, len, n);
@@ -826,14 +853,18 @@ int unet_verify(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const u
             count_on_host(c, (const u32*)c->pinned[1], n);
             return UNET_OK;
         }
+        // (device memory is only needed on this side of the decision)
+        if ((rc = ensure(c, c->d_arena, res_at + (u64)n * 4u))) return rc;
         uint8_t* dev = (uint8_t*)c->d_arena.p;
         HIP_TRY(hipMemcpyAsync(dev, c->pinned[0], im.total, hipMemcpyHostToDevice, c->s_comp));
         u32* d_out = (u32*)(dev + res_at);
         const int tile = c->tile_override ? c->tile_override : tile_for(im.sum_len / n, true, im.max_len);
         if ((rc = launch_verify(c->s_comp, image_batch(dev, im, off16 != nullptr, stride16, n), iface, tile, d_out))) return rc;
+        // the counting kernel goes ahead of the copy: when the wait below ends nothing reads d_out any more, so the
+        // next call (of any context that shares the memory) may overwrite it
+        if ((rc = count_into_ctx(c, c->s_comp, d_out, n))) return rc;
         HIP_TRY(hipMemcpyAsync(c->pinned[1], d_out, (size_t)n * 4u, hipMemcpyDeviceToHost, c->s_comp));
         HIP_TRY(hipEventRecord(c->results_ready, c->s_comp));
-        if ((rc = count_into_ctx(c, c->s_comp, d_out, n))) return rc;
         HIP_TRY(hipEventSynchronize(c->results_ready));
         memcpy(out, c->pinned[1], (size_t)n * 4u);
         return UNET_OK;
@@ -881,22 +912,34 @@ int unet_verify_async(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, c
     const int tile = c->tile_override ? c->tile_override : tile_for(im.sum_len / n, true, im.max_len);
     const int tile_here = in_place_tile(tile);
     sl.in_place = read_in_place(c, im.total, n, tile_here);
-    if (!sl.in_place && (rc = ensure(c, sl.dev, need))) return rc;
+    // the slot's device image grows in steps of two, so that a steady stream of batches soon stops reallocating
+    // (a hipFree waits for the whole device, the other slot's batch included)
+    if (!sl.in_place && need > sl.dev.cap && (rc = ensure(c, sl.dev, need > 2u * sl.dev.cap ? need : 2u * sl.dev.cap))) return rc;
     // the caller's buffers are free again when this returns: everything the GPU reads sits in the pinned image
     fill_image(c, (uint8_t*)sl.pin, im, arena, off16, len, n);
-    if (sl.in_place) {
-        // (see unet_verify: the kernel works on the pinned image itself)
-        const uint8_t* hd = (const uint8_t*)sl.pin_dev;
-        if ((rc = launch_verify(sl.s, image_batch(hd, im, off16 != nullptr, stride16, n), iface, tile_here, (u32*)((uint8_t*)sl.pin_dev + res_at)))) return rc;
-        HIP_TRY(hipEventRecord(sl.done, sl.s));
-    } else {
-        uint8_t* dev = (uint8_t*)sl.dev.p;
-        HIP_TRY(hipMemcpyAsync(dev, sl.pin, im.total, hipMemcpyHostToDevice, sl.s));
-        u32* d_out = (u32*)(dev + res_at);
-        if ((rc = launch_verify(sl.s, image_batch(dev, im, off16 != nullptr, stride16, n), iface, tile, d_out))) return rc;
-        HIP_TRY(hipMemcpyAsync((uint8_t*)sl.pin + res_at, d_out, (size_t)n * 4u, hipMemcpyDeviceToHost, sl.s));
-        HIP_TRY(hipEventRecord(sl.done, sl.s));
-        if ((rc = count_into_ctx(c, sl.s, d_out, n))) return rc;
+    // From the first command queued on the slot's stream on, a failure must not hand the slot back while the GPU
+    // may still be reading its pinned image: wait for the stream before reporting it.
+    auto enqueue = [&]() -> int {
+        int rc2;
+        if (sl.in_place) {
+            // (see unet_verify: the kernel works on the pinned image itself)
+            const uint8_t* hd = (const uint8_t*)sl.pin_dev;
+            if ((rc2 = launch_verify(sl.s, image_batch(hd, im, off16 != nullptr, stride16, n), iface, tile_here, (u32*)((uint8_t*)sl.pin_dev + res_at)))) return rc2;
+            HIP_TRY(hipEventRecord(sl.done, sl.s));
+        } else {
+            uint8_t* dev = (uint8_t*)sl.dev.p;
+            HIP_TRY(hipMemcpyAsync(dev, sl.pin, im.total, hipMemcpyHostToDevice, sl.s));
+            u32* d_out = (u32*)(dev + res_at);
+            if ((rc2 = launch_verify(sl.s, image_batch(dev, im, off16 != nullptr, stride16, n), iface, tile, d_out))) return rc2;
+            if ((rc2 = count_into_ctx(c, sl.s, d_out, n))) return rc2;
+            HIP_TRY(hipMemcpyAsync((uint8_t*)sl.pin + res_at, d_out, (size_t)n * 4u, hipMemcpyDeviceToHost, sl.s));
+            HIP_TRY(hipEventRecord(sl.done, sl.s));
+        }
+        return UNET_OK;
+    };
+    if ((rc = enqueue())) {
+        (void)hipStreamSynchronize(sl.s);  // g_err keeps the first failure's text
+        return rc;
     }
     sl.busy = true;
     sl.seq = (sl.seq + 1u) & 0xffffffu;
@@ -942,6 +985,9 @@ int unet_verify_static(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, 
         return fail(UNET_E_RANGE, "unet_verify_static takes records inside the arena's first %llu bytes, these reach byte %llu (use unet_verify)",
                     (unsigned long long)kStaticMaxArena, (unsigned long long)im.used);
     HIP_TRY(hipSetDevice(c->device));
+    // every context on this GPU shares the one array: a call that finds another one inside is refused
+    StaticInUse in_use(c->device);
+    if (!in_use.mine) return fail(UNET_E_BUSY, "unet_verify_static: another call is using device %d's static array", c->device);
     // one staging image [len | off16 | arena], one H2D copy, one launch, one D2H copy, all on the compute stream
     HIP_TRY(hipEventSynchronize(c->pinned_free[0]));
     HIP_TRY(hipEventSynchronize(c->pinned_free[1]));
@@ -951,9 +997,10 @@ int unet_verify_static(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, 
     u32* d_out = (u32*)(dev + kStaticOutAt);
     const int tile = c->tile_override ? c->tile_override : tile_for(im.sum_len / n, true, im.max_len);
     if ((rc = launch_verify(c->s_comp, image_batch(dev, im, off16 != nullptr, stride16, n), iface, tile, d_out))) return rc;
+    // counted ahead of the copy, so that nothing reads the shared array once the wait below has ended
+    if ((rc = count_into_ctx(c, c->s_comp, d_out, n))) return rc;
     HIP_TRY(hipMemcpyAsync(c->pinned[1], d_out, (size_t)n * 4u, hipMemcpyDeviceToHost, c->s_comp));
     HIP_TRY(hipEventRecord(c->results_ready, c->s_comp));
-    if ((rc = count_into_ctx(c, c->s_comp, d_out, n))) return rc;
     HIP_TRY(hipEventSynchronize(c->results_ready));
     memcpy(out, c->pinned[1], (size_t)n * 4u);
     return UNET_OK;
@@ -970,6 +1017,7 @@ int unet_generate_dev(unet_ctx* ctx, void* stream, uint8_t* d_arena, uint64_t ar
     Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
     if (arena_too_small(arena_bytes)) return fail(UNET_E_INVAL, "arena must hold at least 16 bytes");
     b.tile_n = (u32)pick_tile(ctx, arena_bytes, stride16, n);
+    if ((rc = check_tiles(n, b.tile_n))) return rc;
     const dim3 grid(tiles_grid(n, b.tile_n));
     switch (kernel_tile((int)b.tile_n)) {
         case 16: hipLaunchKernelGGL((k_generate<16, true>), grid, dim3(kBlock), 0, pick(ctx, stream), b, d_arena, (u32*)nullptr, d_status); break;
@@ -991,6 +1039,7 @@ int unet_checksum_fields_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena
     Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
     if (arena_too_small(arena_bytes)) return fail(UNET_E_INVAL, "arena must hold at least 16 bytes");
     b.tile_n = (u32)pick_tile(ctx, arena_bytes, stride16, n);
+    if ((rc = check_tiles(n, b.tile_n))) return rc;
     const dim3 grid(tiles_grid(n, b.tile_n));
     switch (kernel_tile((int)b.tile_n)) {
         case 16: hipLaunchKernelGGL((k_generate<16, false>), grid, dim3(kBlock), 0, pick(ctx, stream), b, (uint8_t*)nullptr, (u32*)d_fields, d_status); break;
@@ -1026,7 +1075,7 @@ int unet_generate(unet_ctx* c, uint8_t* arena, uint64_t arena_bytes, const uint3
     if (!off16 && stride16 == 0) return fail(UNET_E_INVAL, "need an offset table or a non-zero stride");
     HIP_TRY(hipSetDevice(c->device));
     int rc;
-    if (arena_bytes + 2ull * n * 4u + 32u <= kStageBytes && (u64)n * 5u + 16u <= kStageBytes) {
+    if (arena_bytes + 2ull * n * 4u + 64u <= kStageBytes && (u64)n * 5u + 16u <= kStageBytes) {
         // a few packets: the kernel reads them where the staging image lies and leaves values and status in the
         // other pinned buffer (see unet_verify)
         Image im;
@@ -1095,6 +1144,7 @@ int unet_tx_build_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload_aren
     int tile = tx_tile_for(pick_mean(ctx, payload_arena_bytes, payload_stride16, n));
     if (ctx->tx_tile_override) tile = ctx->tx_tile_override;
     b.tile_n = (u32)tile;  // fewer packets per wave than the smallest instantiation: that kernel, part of its lanes
+    if ((rc = check_tiles(n, b.tile_n))) return rc;
     if (iface->mode == UNET_MODE_L2) {
         if (tile <= 8) UNET_TX_LAUNCH(MODE_L2, 8);
         else if (tile == 16) UNET_TX_LAUNCH(MODE_L2, 16);
@@ -1442,9 +1492,15 @@ int unet_synth_indexed_dev(unet_ctx* ctx, void* stream, int kind, uint64_t seed,
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = pick(ctx, stream);
     if (kind != UNET_SYNTH_IPV4_HDR20) {
-        const u32 grid = (n + (kBlock / kWave) - 1) / (kBlock / kWave);
-        hipLaunchKernelGGL(k_synth_raw, dim3(grid), dim3(kBlock), 0, s, kind, seed, first_idx, d_rel_idx, n, d_off16, d_len, d_arena, arena_bytes);
-        HIP_TRY(hipGetLastError());
+        // one wave per record, and a launch holds fewer than 2^32 threads: slices of 2^25 records
+        constexpr u32 kSlice = 1u << 25;
+        for (u32 at = 0; at < n; at += kSlice) {
+            const u32 m = n - at < kSlice ? n - at : kSlice;
+            const u32 grid = (m + (kBlock / kWave) - 1) / (kBlock / kWave);
+            hipLaunchKernelGGL(k_synth_raw, dim3(grid), dim3(kBlock), 0, s, kind, seed, d_rel_idx ? first_idx : first_idx + at,
+                               d_rel_idx ? d_rel_idx + at : nullptr, m, d_off16 + at, d_len + at, d_arena, arena_bytes);
+            HIP_TRY(hipGetLastError());
+        }
     }
     hipLaunchKernelGGL(k_synth_hdr, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, kind, seed, first_idx, d_rel_idx, n,
                        iface->unicast, iface->broadcast, d_off16, d_len, d_arena, arena_bytes);

@@ -1,5 +1,5 @@
 """Multi-GPU decomposition of the path: records are independent, so ranks take disjoint records and the
-only thing that ever crosses GPUs is the per-verdict counter vector (one all-reduce, ~256 bytes).
+only thing that ever crosses GPUs is the per-verdict counter vector (one all-reduce, 320 bytes).
 
 Two placements are provided:
   * flow hash     -- rank = flow_hash5(src, dst, proto, sport, dport) % world, so all frames of a flow
@@ -41,14 +41,14 @@ def allreduce_counts(counts: torch.Tensor, dist=None) -> torch.Tensor:
     """Sum the V_COUNT verdict counters over all ranks (in place); no-op without a process group."""
     if counts.numel() != V_COUNT or counts.dtype != torch.int64:
         raise ValueError(f"expected {V_COUNT} int64 counters")
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():  # (also with one rank: the collective is the code path under test then)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     return counts
 
 
 def max_over_ranks(seconds: float, device, dist=None) -> float:
     """The job's time is the slowest rank's time."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
