@@ -40,6 +40,8 @@ import unet_amd
 from unet_amd import Verdict, shard
 
 SEED = 0x756E6574
+TX_LAYOUT = "auto"   # --tx-layout: where the transmit workloads put their packets ("packed", or "lines" = on 128-byte lines)
+TX_FILL_LINES = 1    # UNET_TX_FILL_LINES
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
 
 WORKLOADS = {
@@ -221,6 +223,9 @@ class Batch:
             self.desc = torch.from_numpy(desc.view(np.uint8).reshape(-1)).cuda()
             self.plen = torch.clamp(self.len - 28, min=0)
             oslots = (self.plen.to(torch.int64) + 28 + 15) // 16
+            self.tx_flags = 0
+            if TX_LAYOUT == "lines":
+                oslots, self.tx_flags = (oslots + 7) // 8 * 8, TX_FILL_LINES
             self.ooff = (torch.cumsum(oslots, 0) - oslots).to(torch.int32)
             self.out_bytes = int(oslots.sum().item()) * 16
             self.out_arena = torch.zeros(self.out_bytes + 16, dtype=torch.uint8, device="cuda")
@@ -236,8 +241,11 @@ class Batch:
             self.rx = unet_amd.Iface("198.51.100.7", "255.255.255.0", mac=bytes.fromhex("02c0ffee0007"), mode=1 if l2 else 0)
             self.tx_ifc = ifc.replace(mode=1 if l2 else 0)
             self.ostride = 95 if l2 else 94  # 1514 / 1500 bytes in 16-byte slots
-            if os.environ.get("UNET_BENCH_TX_OSTRIDE"):  # experiment: packets on 128-byte lines (96)
-                self.ostride = int(os.environ["UNET_BENCH_TX_OSTRIDE"])
+            self.tx_flags = 0
+            if op == "txbuild" and TX_LAYOUT == "lines":
+                # every packet starts on a 128-byte line (unet_tx_layout_aligned, align16 = 8) and the kernel may write
+                # its last line whole: the layout the library recommends for payloads above about 1 KiB
+                self.ostride, self.tx_flags = 96, TX_FILL_LINES
             desc = np.zeros(self.n, dtype=TX_DESC_DTYPE)
             desc["dst_mac"] = np.frombuffer(bytes(self.rx.mac), dtype=np.uint8)
             rng = np.random.default_rng(SEED + first_idx)
@@ -294,11 +302,11 @@ class Batch:
         if self.op == "tximix":
             self.ctx.tx_build_dev(self.arena.data_ptr(), self.nbytes, self.off.data_ptr(), 0, self.plen.data_ptr(), self.desc.data_ptr(),
                                   self.n, self.tx_ifc, self.out_arena.data_ptr(), self.out_bytes, self.ooff.data_ptr(),
-                                  self.olen.data_ptr(), self.status.data_ptr(), self.stream)
+                                  self.olen.data_ptr(), self.status.data_ptr(), self.stream, flags=self.tx_flags)
             return
         self.ctx.tx_build_dev(self.arena.data_ptr(), self.nbytes, None, 94, self.plen.data_ptr(), self.desc.data_ptr(), self.n,
                               self.tx_ifc, self.out_arena.data_ptr(), self.out_bytes, self.ooff.data_ptr(), self.olen.data_ptr(),
-                              self.status.data_ptr(), self.stream)
+                              self.status.data_ptr(), self.stream, flags=self.tx_flags)
 
     def counts(self):
         d_cnt = torch.zeros(unet_amd.V_COUNT, dtype=torch.int64, device="cuda")
@@ -327,6 +335,9 @@ def main():
     ap.add_argument("--emulate-rank", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--all-on-gpu0", action="store_true", help="rehearsal on a one-GPU box: every rank uses cuda:0")
+    ap.add_argument("--tx-layout", default="auto", choices=["auto", "packed", "lines"],
+                    help="txbuild / tximix: output packets packed on 16-byte boundaries, or on 128-byte lines with UNET_TX_FILL_LINES "
+                         "(auto: lines for txbuild, whose payloads are above 1 KiB; packed for tximix)")
     ap.add_argument("--dry-run", action="store_true", help="start the ranks, rendezvous, print who is there, stop before any GPU call")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group (RCCL with --backend nccl) even with one rank, so that the barrier, the counter "
@@ -337,6 +348,14 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(sys.argv[1:], args.gpus))
+    # Native libraries write to file descriptor 1 as they please (RCCL prints a version banner there when it is
+    # initialised): from here on descriptor 1 is the error stream, and the one JSON line goes to the real one.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -361,7 +380,7 @@ def main():
             seen = [int(x) - 1 for x in t.tolist()]
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": seen, "workload": args.workload}), flush=True)
+            emit({"dry_run": True, "n_gpus": world, "ranks": seen, "workload": args.workload})
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the offload has no CPU path")
@@ -385,6 +404,8 @@ def main():
             dist.init_process_group(args.backend, timeout=limit, rank=rank, world_size=world)
     shard_world, shard_rank = (args.emulate_world, args.emulate_rank) if args.emulate_world else (world, rank)
 
+    global TX_LAYOUT
+    TX_LAYOUT = args.tx_layout if args.tx_layout != "auto" else ("lines" if args.workload == "txbuild" else "packed")
     kind, n_per_gpu, stride16 = WORKLOADS[args.workload]
     if args.stride16 and stride16:
         stride16 = args.stride16
@@ -467,7 +488,7 @@ def main():
             # the CPU path beside every scaling point: rank 0 times it once the GPUs are idle
             if args.cpu_seconds > 0:
                 line["cpu_baseline"] = cpu_baseline(kind, ifc, args.cpu_seconds)
-            print(json.dumps(line), flush=True)
+            emit(line)
         return
 
     # ---- resident batches.  A workload whose arena is not far larger than the 256 MiB Infinity Cache is
@@ -614,7 +635,8 @@ def main():
                        "sharding": sharding, "shard_sizes": [s // rotate for s in all_sizes],
                        "shard_skew_max_over_mean": max(all_sizes) / (sum(all_sizes) / len(all_sizes)),
                        "collectives": f"none on the data path; {unet_amd.V_COUNT} u64 verdict counters all-reduced (RCCL) after the timed region",
-                       "inputs": "generated in HBM by unet_synth_indexed_dev before the timed region"},
+                       "inputs": "generated in HBM by unet_synth_indexed_dev before the timed region",
+                       **({"tx_output_layout": TX_LAYOUT, "tx_output_arena_bytes": b0.out_bytes} if op in ("txbuild", "tximix") else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernels_sha256": kernels_sha256(), "kernel": kernel,
@@ -632,7 +654,7 @@ def main():
         # the CPU path beside every scaling point: rank 0 times it once the GPUs are idle
         if args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(kind, ifc, args.cpu_seconds)
-        print(json.dumps(line), flush=True)
+        emit(line)
 
 
 if __name__ == "__main__":

@@ -132,7 +132,7 @@ def test_oracle_tx_build_status_codes():
 
 # ------------------------------------------------------------------------------------------ GPU
 
-def _gpu_build(offload, arena, off16, plen, desc, ifc, ooff, obytes, fill=0xAB, stride16=0):
+def _gpu_build(offload, arena, off16, plen, desc, ifc, ooff, obytes, fill=0xAB, stride16=0, flags=0):
     import torch
     assert torch.cuda.is_available()
     st = torch.cuda.Stream()
@@ -147,7 +147,7 @@ def _gpu_build(offload, arena, off16, plen, desc, ifc, ooff, obytes, fill=0xAB, 
     torch.cuda.synchronize()
     offload.tx_build_dev(d_arena.data_ptr(), arena.nbytes, 0 if d_off is None else d_off.data_ptr(), stride16, d_len.data_ptr(),
                          d_desc.data_ptr(), len(plen), ifc, d_out.data_ptr(), obytes, d_ooff.data_ptr(), d_olen.data_ptr(),
-                         d_status.data_ptr(), stream=st.cuda_stream)
+                         d_status.data_ptr(), stream=st.cuda_stream, flags=flags)
     st.synchronize()
     return d_out.cpu().numpy(), d_olen.cpu().numpy().view(np.uint32), d_status.cpu().numpy()
 
@@ -241,6 +241,47 @@ def test_tx_build_into_a_line_aligned_layout(offload, mode):
     nxt = np.append(ooff[1:].astype(np.int64), obytes // 16)
     for s0, s1 in zip(slots, nxt):
         assert (got[16 * int(s0):16 * int(s1)] == 0xAB).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [unet_amd.MODE_L3, unet_amd.MODE_L2])
+@pytest.mark.parametrize("align16", [8, 1, 2])
+def test_tx_build_may_fill_each_packets_last_line(offload, mode, align16):
+    """UNET_TX_FILL_LINES: the packet bytes are the oracle's; from a packet's end to the next 128-byte line of the
+    output arena every byte is either untouched or zero (the kernel may, but need not, write the line whole); no
+    byte past that line changes, whatever the layout (on lines, packed, on 32-byte boundaries), and nothing past
+    out_arena_bytes."""
+    from unet_amd._ffi import TX_FILL_LINES
+    rng = np.random.default_rng(43 + mode + align16)
+    ifc = unet_amd.Iface("192.0.2.2", "255.255.255.0", mac=bytes.fromhex("02aabbccddee"), mode=mode)
+    lens = LENS + [int(x) for x in rng.integers(0, 3000, size=1500)] + [1472] * 40 + [2000] * 20 + [4000, 6000, 8972, 20000, 65507]
+    desc, payloads = make_batch(rng, lens, ifc)
+    arena, off16, plen = unet_amd.pack_arena(payloads, pad_byte=0x77)
+    if align16 == 8:
+        ooff, obytes = tx_out_layout(plen, mode, align16=8)
+    else:
+        # slots a line apart or more, starting off the lines: the filled range ends at the line, not at the slot
+        slots = ((tx_frame_len(plen, mode) + 15) // 16 + 7) // 8 * 8 + 8
+        ooff = (np.cumsum(slots) - slots + align16).astype(np.uint32)
+        obytes = int(slots.sum() + 8) * 16
+    exp, exp_len, exp_status = O.tx_build_batch(arena, off16, plen, desc, ifc, ooff, obytes)
+    got, got_len, got_status = _gpu_build(offload, arena, off16, plen, desc, ifc, ooff, obytes, flags=TX_FILL_LINES)
+    assert (got_status == exp_status).all() and (got_status == 0).all() and (got_len == exp_len).all()
+    touched = np.zeros(obytes, dtype=bool)
+    filled = 0
+    for o, l in zip(ooff, exp_len):
+        a, b = 16 * int(o), 16 * int(o) + int(l)
+        assert (got[a:b] == exp[a:b]).all(), (int(o), int(l))
+        line_end = min((b + 127) // 128 * 128, obytes)
+        tail = got[b:line_end]
+        chunk_end = (b + 15) // 16 * 16
+        assert (got[b:chunk_end] == 0).all()                     # the packet's own last chunk is zero-padded
+        rest = got[chunk_end:line_end].reshape(-1, 16)
+        assert ((rest == 0).all(axis=1) | (rest == 0xAB).all(axis=1)).all(), (int(o), int(l))
+        filled += int((rest == 0).all(axis=1).sum())
+        touched[a:line_end] = True
+    assert (got[:obytes][~touched] == 0xAB).all() and (got[obytes:] == 0xAB).all()
+    assert filled > 0  # the permission is used
 
 
 @pytest.mark.gpu

@@ -110,6 +110,7 @@ class Iface:
 TX_DESC_DTYPE = np.dtype([("src", "<u4"), ("dst", "<u4"), ("l4a", "<u2"), ("l4b", "<u2"), ("values", "<u4"), ("ip_id", "<u2"),
                           ("proto", "u1"), ("reserved0", "u1"), ("dst_mac", "u1", (6,)), ("reserved1", "u1", (2,))])
 TX_OK, TX_E_PROTO, TX_E_TOO_LONG, TX_E_RANGE = 0, 1, 2, 3
+TX_FILL_LINES = 1  # unet_tx_build_opts_dev: packets' last 128-byte lines may be written whole (zeros behind the packet)
 
 # unet_tcp_flow, 32 bytes
 TCP_FLOW_DTYPE = np.dtype([("src", "<u4"), ("dst", "<u4"), ("ports", "<u4"), ("next_seq", "<u4"), ("state", "<u4"), ("segments", "<u4"),
@@ -164,6 +165,8 @@ _SIGS = {
     "unet_generate": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, _u8p]),
     "unet_tx_build_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, _vp, C.c_uint32, C.POINTER(_IfaceC), _u8p,
                                     C.c_uint64, _u32p, _u32p, _u8p]),
+    "unet_tx_build_opts_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, _vp, C.c_uint32, C.POINTER(_IfaceC), _u8p,
+                                         C.c_uint64, _u32p, _u32p, _u8p, C.c_uint32]),
     "unet_tx_layout": (C.c_int, [_u32p, C.c_uint32, C.c_int, _u32p, C.POINTER(C.c_uint64)]),
     "unet_tx_layout_aligned": (C.c_int, [_u32p, C.c_uint32, C.c_int, C.c_uint32, _u32p, C.POINTER(C.c_uint64)]),
     "unet_tx_build": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, _vp, C.c_uint32, C.POINTER(_IfaceC), _u8p, C.c_uint64,
@@ -536,8 +539,12 @@ class Offload:
         _check(self.lib.unet_generate_dev(self.h, stream, d_arena, arena_bytes, d_off16, stride16, d_len, n, d_status))
 
     def tx_build_dev(self, d_pay_arena, pay_bytes, d_pay_off16, pay_stride16, d_pay_len, d_desc, n, iface: Iface, d_out_arena,
-                     out_bytes, d_out_off16, d_out_len, d_status, stream=None):
+                     out_bytes, d_out_off16, d_out_len, d_status, stream=None, flags: int = 0):
         ic = iface.c()
+        if flags:
+            _check(self.lib.unet_tx_build_opts_dev(self.h, stream, d_pay_arena, pay_bytes, d_pay_off16, pay_stride16, d_pay_len, d_desc, n,
+                                                   C.byref(ic), d_out_arena, out_bytes, d_out_off16, d_out_len, d_status, flags))
+            return
         _check(self.lib.unet_tx_build_dev(self.h, stream, d_pay_arena, pay_bytes, d_pay_off16, pay_stride16, d_pay_len, d_desc, n,
                                           C.byref(ic), d_out_arena, out_bytes, d_out_off16, d_out_len, d_status))
 

@@ -12,6 +12,7 @@ namespace unetdev {
 #define UNET_BLOCK 256
 #endif
 constexpr u32 kBlock = UNET_BLOCK;  // 4 waves
+constexpr u32 kTxFillLines = 1;  // = UNET_TX_FILL_LINES of the C header
 constexpr u32 UNET_TX_OK_ = 0, UNET_TX_E_PROTO_ = 1, UNET_TX_E_TOO_LONG_ = 2, UNET_TX_E_RANGE_ = 3;  // = UNET_TX_* of the C header
 constexpr u32 kMaxLen = 65535;   // IPv4 maximum (src/protocols/ipv4.rs:18), loopback MTU (src/devices/loopback.rs:16)
 
@@ -1441,7 +1442,7 @@ template <int MODE, int TILE>
 __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx_build(Batch pay, const TxDesc* __restrict__ desc, IfaceDev ifc,
                                                      uint8_t* __restrict__ out_arena, u64 out_bytes,
                                                      const u32* __restrict__ out_off16, u32* __restrict__ out_len,
-                                                     uint8_t* __restrict__ status) {
+                                                     uint8_t* __restrict__ status, u32 flags) {
     constexpr u32 H = MODE == MODE_L2 ? 42u : 28u;   // header bytes in front of the payload
     constexpr u32 SH = MODE == MODE_L2 ? 3u : 2u;    // output chunks that contain header bytes
     constexpr int R = MODE == MODE_L2 ? 6 : 4;       // payload bytes inside the last header chunk
@@ -1468,6 +1469,15 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx
     else if (t.my_len > 65535u - 20u - 8u) st = UNET_TX_E_TOO_LONG_;  // src/transport/udp.rs:174-180
     else if ((u64)my_oslot * 16u + (((u64)frame_len + 15u) & ~15ull) > out_bytes) st = UNET_TX_E_RANGE_;
     const bool my_go = t.lane < t.cnt && st == UNET_TX_OK_;
+    // Chunks this packet's stores may cover, as a length: the packet itself, or -- when the caller has said that
+    // nothing else lives between a packet's end and the next 128-byte line of the output arena (kTxFillLines) -- up
+    // to that line, so that the packet's last line is written whole (zeros behind the packet) instead of in part.
+    u32 store_len = frame_len;
+    if ((flags & kTxFillLines) != 0u) {
+        const u32 end = my_oslot + ((frame_len + 15u) >> 4);
+        const u32 upto = (end + 7u) & ~7u;
+        if (upto >= end && (u64)upto * 16u <= out_bytes) store_len = (upto - my_oslot) * 16u;
+    }
     const bool my_small = UNET_TX_SMALL_PATH && my_go && t.my_len <= 16u * kTxSmallChunks;
     // payloads of up to 4*W - SH chunks: the packet fits the four steps of a group of W lanes
     const bool my_mid = UNET_TX_MID_PATH && my_go && !my_small && t.my_len <= 16u * (kWave - SH);
@@ -1553,9 +1563,10 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx
 
     // ---- mid-size payloads, 16, 8 or 4 packets at a time (the register buffers are free again afterwards)
     if (mid_mask != 0ull) {
-        if (UNET_TX_G4) tx_rows_path<4, R, SH>(pay, t, my_g4, frame_len, my_oslot, my_partial, my_udp, list, out_arena, park);
-        tx_rows_path<8, R, SH>(pay, t, my_g8, frame_len, my_oslot, my_partial, my_udp, list, out_arena, park);
-        tx_rows_path<16, R, SH>(pay, t, my_mid && !my_g4 && !my_g8, frame_len, my_oslot, my_partial, my_udp, list, out_arena, park);
+        // (a group of W lanes covers 4 W chunks, a multiple of eight: the filled-up length still fits)
+        if (UNET_TX_G4) tx_rows_path<4, R, SH>(pay, t, my_g4, store_len, my_oslot, my_partial, my_udp, list, out_arena, park);
+        tx_rows_path<8, R, SH>(pay, t, my_g8, store_len, my_oslot, my_partial, my_udp, list, out_arena, park);
+        tx_rows_path<16, R, SH>(pay, t, my_mid && !my_g4 && !my_g8, store_len, my_oslot, my_partial, my_udp, list, out_arena, park);
         if (any) {
 #pragma unroll
             for (int k = 0; k < D - 1; ++k) UNET_NEXT(buf[k])
@@ -1570,7 +1581,7 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx
     // ---- three register buffers in rotation, as in tile_sums: the loads of the next two payloads are
     // in flight while one packet is assembled and stored
 #define UNET_CONSUME(X)                                                              \
-    tx_build_one<R, SH>(X, t.lane, rdlane(frame_len, X.j),                           \
+    tx_build_one<R, SH>(X, t.lane, rdlane(store_len, X.j),                           \
                         reinterpret_cast<u32x4*>(out_arena + (u64)rdlane(my_oslot, X.j) * 16u), park + X.j * SH, \
                         rdlane(my_partial, X.j), rdlane((u32)my_udp, X.j) != 0u);
     if (any) {

@@ -1127,7 +1127,18 @@ int unet_tx_build_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload_aren
                       const uint32_t* d_payload_off16, uint32_t payload_stride16, const uint32_t* d_payload_len,
                       const unet_tx_desc* d_desc, uint32_t n, const unet_iface* iface, uint8_t* d_out_arena,
                       uint64_t out_arena_bytes, const uint32_t* d_out_off16, uint32_t* d_out_len, uint8_t* d_status) {
+    return unet_tx_build_opts_dev(ctx, stream, d_payload_arena, payload_arena_bytes, d_payload_off16, payload_stride16, d_payload_len, d_desc, n,
+                                  iface, d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status, 0u);
+}
+
+int unet_tx_build_opts_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload_arena, uint64_t payload_arena_bytes,
+                           const uint32_t* d_payload_off16, uint32_t payload_stride16, const uint32_t* d_payload_len,
+                           const unet_tx_desc* d_desc, uint32_t n, const unet_iface* iface, uint8_t* d_out_arena,
+                           uint64_t out_arena_bytes, const uint32_t* d_out_off16, uint32_t* d_out_len, uint8_t* d_status,
+                           uint32_t flags) {
     static_assert(sizeof(unet_tx_desc) == sizeof(TxDesc), "descriptor layout");
+    static_assert(UNET_TX_FILL_LINES == kTxFillLines, "flag values");
+    if ((flags & ~(uint32_t)UNET_TX_FILL_LINES) != 0u) return fail(UNET_E_INVAL, "unknown flag bits 0x%x", flags & ~(uint32_t)UNET_TX_FILL_LINES);
     static_assert(UNET_TX_E_PROTO == UNET_TX_E_PROTO_ && UNET_TX_E_TOO_LONG == UNET_TX_E_TOO_LONG_ && UNET_TX_E_RANGE == UNET_TX_E_RANGE_, "status codes");
     int rc = check_batch(ctx, d_payload_arena, d_payload_off16, payload_stride16, d_payload_len, n);
     if (rc) return rc;
@@ -1140,7 +1151,7 @@ int unet_tx_build_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload_aren
     const IfaceDev ifc = to_dev(iface);
 #define UNET_TX_LAUNCH(M, T)                                                                                             \
     hipLaunchKernelGGL((k_tx_build<M, T>), dim3(tiles_grid(n, b.tile_n)), dim3(kBlock), 0, pick(ctx, stream), b, (const TxDesc*)d_desc, ifc, \
-                       d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status)
+                       d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status, flags)
     int tile = tx_tile_for(pick_mean(ctx, payload_arena_bytes, payload_stride16, n));
     if (ctx->tx_tile_override) tile = ctx->tx_tile_override;
     b.tile_n = (u32)tile;  // fewer packets per wave than the smallest instantiation: that kernel, part of its lanes
