@@ -438,6 +438,10 @@ uint32_t unet_synth_flow_hash(int kind, uint64_t seed, uint64_t idx, const unet_
  * one u32 per workgroup (at least 4096 slots). */
 int unet_stream_read_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t bytes,
                          uint32_t* d_sink);
+/* The same read as short-lived wavefronts that own 24 KiB each (the shape of the record kernels' own reads).
+ * A benchmark takes the better of the two as what a pure read of its buffer attains on that GPU. */
+int unet_stream_read_pieces_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t bytes,
+                                uint32_t* d_sink);
 /* ------------------------------------------------ arena packing (host code, no GPU involved) */
 /* Bytes an arena needs for n records of these lengths, each padded to a 16-byte boundary (at least 16). */
 int unet_pack_size(const uint32_t* len, uint32_t n, uint64_t* arena_bytes);

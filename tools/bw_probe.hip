@@ -51,6 +51,16 @@ __global__ void k_slab(const u32x4* __restrict__ buf, u64 n, u32* sink) {
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// pseudo-random contents (splitmix64 of the word index): does what is read change how fast it is read?
+__global__ void k_fill_random(u64* buf, u64 nwords) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (u64)gridDim.x * blockDim.x) {
+        u64 z = i * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        buf[i] = z ^ (z >> 31);
+    }
+}
+
 template <typename F>
 double timeit(F f, int iters) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -69,9 +79,21 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d, bytes)); CK(hipMalloc(&sink, 4096));
     CK(hipMemset(d, 0x5a, bytes));
     const u64 n = bytes / 16;
-    printf("buffer %.2f GB\n", bytes / 1e9);
+    const bool random_fill = argc > 2 && argv[2][0] == 'r';
+    if (random_fill) hipLaunchKernelGGL(k_fill_random, dim3(65536), dim3(256), 0, 0, (u64*)d, bytes / 8);
+    CK(hipDeviceSynchronize());
+    printf("buffer %.2f GB, %s\n", bytes / 1e9, random_fill ? "pseudo-random contents" : "every byte 0x5a");
 #define RUN(name, K, grid, block) { double ms = timeit([&] { hipLaunchKernelGGL(K, dim3(grid), dim3(block), 0, 0, (const u32x4*)d, n, sink); }, 10); \
         printf("%-28s grid %6d block %4d : %7.3f ms  %7.1f GB/s\n", name, grid, block, ms, bytes / ms / 1e6); fflush(stdout); }
+    const bool brief = argc > 3;
+    if (brief) {
+        for (int grid : {4096, 8192}) {
+            RUN("gs U4 nt", (k_gs<4, true>), grid, 256);
+            RUN("slab U4", (k_slab<4, false>), grid, 256);
+            RUN("slab U4 nt", (k_slab<4, true>), grid, 256);
+        }
+        return 0;
+    }
     for (int block : {256, 512, 1024}) {
         for (int grid : {1024, 2048, 4096, 8192, 16384, 65536}) {
             if ((long)grid * block > 16384L * 1024) continue;

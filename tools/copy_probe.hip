@@ -182,6 +182,15 @@ double timeit(F f, int iters) {
     return ms / iters;
 }
 
+__global__ void k_fill_random(u64* buf, u64 nwords) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (u64)gridDim.x * blockDim.x) {
+        u64 z = i * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        buf[i] = z ^ (z >> 31);
+    }
+}
+
 int main(int argc, char** argv) {
     const u64 bytes = argc > 1 ? strtoull(argv[1], 0, 10) : (3ull << 30);
     uint8_t *s, *d;
@@ -190,7 +199,14 @@ int main(int argc, char** argv) {
     CK(hipMemset(s, 0x5a, bytes));
     CK(hipMemset(d, 0, bytes));
     const u64 n = bytes / 16;
-    printf("copy %.2f GB -> %.2f GB per launch; GB/s counts read + written bytes\n", bytes / 1e9, bytes / 1e9);
+    // argv[2] = "random": the source holds pseudo-random bytes instead of one repeated byte (what is moved changes
+    // how fast it moves on this part: fewer bits toggle on a constant buffer); argv[3] present: the shapes that
+    // matter only (pieces per wave, 1500-byte records, the library copy)
+    const bool random_fill = argc > 2 && argv[2][0] == 'r', brief = argc > 3;
+    if (random_fill) hipLaunchKernelGGL(k_fill_random, dim3(65536), dim3(256), 0, 0, (u64*)s, bytes / 8);
+    CK(hipDeviceSynchronize());
+    printf("copy %.2f GB -> %.2f GB per launch (%s); GB/s counts read + written bytes\n", bytes / 1e9, bytes / 1e9,
+           random_fill ? "pseudo-random contents" : "every byte 0x5a");
 #define REPORT(name, grid, block, ms) { printf("%-34s grid %6d block %4d : %7.3f ms  %7.1f GB/s\n", name, grid, block, ms, 2.0 * bytes / (ms) / 1e6); fflush(stdout); }
 #define SLAB(U, LD, ST, grid, block) { double ms = timeit([&] { hipLaunchKernelGGL((k_copy_slab<U, LD, ST>), dim3(grid), dim3(block), 0, 0, s, d, n); }, 6); \
         REPORT("slab U" #U " ld" #LD " st" #ST, grid, block, ms); }
@@ -200,6 +216,7 @@ int main(int argc, char** argv) {
         double ms = timeit([&] { CK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, 0)); }, 6);
         REPORT("hipMemcpy D2D", 0, 0, ms);
     }
+    if (!brief) {
     // cache-policy bits on the loads and stores, fixed shape
     SLAB(4, 0, 0, 4096, 256) SLAB(4, 2, 0, 4096, 256) SLAB(4, 0, 2, 4096, 256) SLAB(4, 2, 2, 4096, 256)
     SLAB(4, 2, 1, 4096, 256) SLAB(4, 2, 3, 4096, 256) SLAB(4, 2, 16, 4096, 256) SLAB(4, 2, 17, 4096, 256)
@@ -219,6 +236,7 @@ int main(int argc, char** argv) {
         ms = timeit([&] { hipLaunchKernelGGL((k_copy_wave4k<0, 0>), dim3(grid), dim3(256), 0, 0, (const u32x4*)s, (u32x4*)d, n); }, 6);
         REPORT("wave per 4 KiB piece ld0 st0", grid, 256, ms);
     }
+    } else { SLAB(4, 2, 2, 4096, 256) SLAB(4, 2, 2, 65536, 256) SLAB(4, 2, 2, 1024, 1024) }
 #define PIECE(P, LD, ST, block) { const u64 pieces = n / (P * 64); const int grid = (int)((pieces + (block / 64) - 1) / (block / 64)); \
         double ms = timeit([&] { hipLaunchKernelGGL((k_copy_piece<P, LD, ST>), dim3(grid), dim3(block), 0, 0, (const u32x4*)s, (u32x4*)d, n); }, 6); \
         REPORT("one " #P " KiB piece per wave ld" #LD " st" #ST, grid, block, ms); }

@@ -192,6 +192,7 @@ _SIGS = {
     "unet_pcap_pack": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _u8p, C.c_uint64, _u32p, _u32p, _u64p, C.c_uint32]),
     "unet_pcap_write": (C.c_int, [_u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.c_uint32, _u8p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "unet_stream_read_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p]),
+    "unet_stream_read_pieces_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p]),
     "unet_stream_copy_dev": (C.c_int, [_vp, _vp, _u8p, _u8p, C.c_uint64]),
 }
 
@@ -581,6 +582,9 @@ class Offload:
 
     def stream_read_dev(self, d_buf, nbytes, d_sink, stream=None):
         _check(self.lib.unet_stream_read_dev(self.h, stream, d_buf, nbytes, d_sink))
+
+    def stream_read_pieces_dev(self, d_buf, nbytes, d_sink, stream=None):
+        _check(self.lib.unet_stream_read_pieces_dev(self.h, stream, d_buf, nbytes, d_sink))
 
     def stream_copy_dev(self, d_src, d_dst, nbytes, stream=None):
         _check(self.lib.unet_stream_copy_dev(self.h, stream, d_src, d_dst, nbytes))

@@ -1697,6 +1697,36 @@ __global__ __launch_bounds__(kBlock) void k_stream_read(const u32x4* __restrict_
     if ((threadIdx.x & 63u) == 0u) atomicAdd(&sink[blockIdx.x & 4095u], acc);
 }
 
+// The same bytes read the way the record kernels read them: short-lived waves, each owning one contiguous piece of
+// kPieceChunks chunks (24 KiB, what a wave of k_verify covers on 1500-byte records), two non-temporal 1 KiB rows
+// requested ahead of the pair being summed.  On some boxes this shape reads faster than the slabs above; the
+// benchmark reports the better of the two as what a pure read of the buffer attains.
+constexpr u32 kPieceChunks = 1536;
+__global__ __launch_bounds__(kBlock) void k_stream_read_pieces(const u32x4* __restrict__ buf, u64 nchunks, u32* __restrict__ sink) {
+    const u32 lane = threadIdx.x & 63u;
+    const u64 wave = (u64)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    const u64 lo = wave * kPieceChunks;
+    if (lo >= nchunks) return;
+    const u64 left = nchunks - lo;
+    const u32 n = left < kPieceChunks ? (u32)left : kPieceChunks;
+    const u32x4* p = buf + lo;
+    const u32 last = n - 1u;
+    u32 acc = 0;
+    // (the second row of a pair with the default policy: the pair the record kernels use, and 1 % faster than two
+    // streaming rows in the probe of that pattern)
+    u32x4 a = ld_stream(p + min(lane, last)), b = p[min(lane + kWave, last)];
+    for (u32 c = 2u * kWave; c < n + 2u * kWave; c += 2u * kWave) {
+        // rows past the piece's end re-read its last chunk (same line, no traffic) and are not summed
+        const u32x4 na = ld_stream(p + min(c + lane, last)), nb = p[min(c + lane + kWave, last)];
+        acc = sum_chunk(zero_unless(a, c - 2u * kWave + lane < n), acc);
+        acc = sum_chunk(zero_unless(b, c - kWave + lane < n), acc);
+        a = na;
+        b = nb;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0u) atomicAdd(&sink[wave & 4095u], acc);
+}
+
 // Read+write yardstick: plain copy with the same access pattern (slab per workgroup, 16 bytes per lane).
 __global__ __launch_bounds__(kBlock) void k_stream_copy(const u32x4* __restrict__ src, u32x4* __restrict__ dst, u64 nchunks) {
     const u64 per = ((nchunks + gridDim.x - 1) / gridDim.x + 63u) & ~63ull;  // slabs start on 1 KiB boundaries

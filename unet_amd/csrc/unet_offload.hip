@@ -1563,6 +1563,19 @@ int unet_stream_read_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint
     return UNET_OK;
 }
 
+int unet_stream_read_pieces_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t bytes, uint32_t* d_sink) {
+    if (!ctx || !d_buf || !d_sink) return fail(UNET_E_INVAL, "null argument");
+    if (((uintptr_t)d_buf & 15u) != 0) return fail(UNET_E_INVAL, "buffer must be 16-byte aligned");
+    const u64 nchunks = bytes / 16, per_block = (u64)kPieceChunks * (kBlock / kWave);
+    const u64 grid = (nchunks + per_block - 1) / per_block;
+    if (grid == 0) return UNET_OK;
+    if (grid * kBlock >= (1ull << 32)) return fail(UNET_E_RANGE, "buffer of %llu bytes is too large for one launch", (unsigned long long)bytes);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_stream_read_pieces, dim3((u32)grid), dim3(kBlock), 0, pick(ctx, stream), (const u32x4*)d_buf, nchunks, d_sink);
+    HIP_TRY(hipGetLastError());
+    return UNET_OK;
+}
+
 /* ---------------------------------------------------------------- arena packing */
 int unet_pack_size(const uint32_t* len, uint32_t n, uint64_t* arena_bytes) {
     if ((n && !len) || !arena_bytes) return fail(UNET_E_INVAL, "null argument");
