@@ -58,6 +58,8 @@ WORKLOADS = {
     "txbuild": (unet_amd.SYNTH_UDP1500, 1 << 22, 94),
     "eth1514": (unet_amd.SYNTH_UDP1500, 1 << 22, 94),
     "tximix": (unet_amd.SYNTH_IMIX, 1 << 23, 0),
+    # extension (no TCP in the reference): verdicts, then per-flow TCP tracking of the accepted segments
+    "tcptrack": (unet_amd.SYNTH_FLOWS, 1 << 24, 0),
 }
 DESCRIPTION = {
     "udp1500": "4,194,304 x 1500-byte IPv4/UDP packets per GPU (BASELINE configs[2])",
@@ -70,6 +72,8 @@ DESCRIPTION = {
     "fields": "transmit-side checksum values of 4,194,304 x 1500-byte IPv4/UDP packets per GPU, packets left untouched (unet_checksum_fields_dev)",
     "txbuild": "4,194,304 x 1500-byte IPv4/UDP packets per GPU built from 1472-byte payloads + descriptors (unet_tx_build_dev)",
     "tximix": "8,388,608 IPv4/UDP packets per GPU built from payloads of IMIX sizes (36-8972 bytes) + descriptors (unet_tx_build_dev)",
+    "tcptrack": "EXTENSION, parity unpinned (the reference has no TCP): 16,777,216 records of the flow trace per GPU judged (unet_verify_dev, ext_tcp) and their "
+                "accepted TCP segments applied to a per-flow table of 4,194,304 slots (unet_tcp_track_ws_dev)",
     "eth1514": "4,194,304 x 1514-byte Ethernet frames per GPU (IPv4/UDP inside, built by unet_tx_build_dev in L2 mode, faults injected), judged in L2 mode",
 }
 
@@ -208,6 +212,15 @@ class Batch:
         elif op in ("generate", "fields"):
             self.alg_bytes += self.n          # 4 bytes of checksum fields + 1 status byte instead of a 4-byte result
             self.status = torch.zeros(self.n, dtype=torch.uint8, device="cuda")
+        elif op == "tcptrack":
+            from unet_amd._ffi import tcp_track_workspace
+            self.table_slots = 1 << 22
+            self.table = torch.zeros(self.table_slots * 32, dtype=torch.uint8, device="cuda")
+            self.seg_state = torch.zeros(self.n, dtype=torch.uint8, device="cuda")
+            self.ws_bytes = tcp_track_workspace(self.n, self.table_slots)
+            self.ws = torch.zeros(self.ws_bytes, dtype=torch.uint8, device="cuda")
+            self.tcp_stats = torch.zeros(2, dtype=torch.int32, device="cuda")
+            self.alg_bytes += 5 * self.n  # the verdict read back and one state byte written per record (sort and table traffic not counted)
         elif op == "tximix":
             # the resident IMIX records serve as payloads: a record of L bytes gives an L-28-byte payload, so the
             # built packets have the IMIX sizes again
@@ -286,6 +299,12 @@ class Batch:
             off_ptr = None if self.stride16 else self.off.data_ptr()
             self.ctx.checksum_fields_dev(self.arena.data_ptr(), self.nbytes, off_ptr, self.stride16, self.len.data_ptr(), self.n,
                                          self.out.data_ptr(), self.status.data_ptr(), self.stream)
+        elif self.op == "tcptrack":
+            self.ctx.verify_dev(self.arena.data_ptr(), self.nbytes, self.off.data_ptr(), 0, self.len.data_ptr(), self.n, self.ifc,
+                                self.out.data_ptr(), self.stream)
+            self.ctx.tcp_track_ws_dev(self.arena.data_ptr(), self.nbytes, self.off.data_ptr(), 0, self.len.data_ptr(), self.out.data_ptr(), self.n,
+                                      self.ifc, self.table.data_ptr(), self.table_slots, self.seg_state.data_ptr(), self.ws.data_ptr(),
+                                      self.ws_bytes, self.tcp_stats.data_ptr(), self.stream)
         elif self.op in ("txbuild", "tximix"):
             self.build()
         elif self.op == "eth1514":
@@ -411,7 +430,7 @@ def main():
         stride16 = args.stride16
     if args.frames:
         n_per_gpu = args.frames
-    ext_tcp = (args.workload in ("imix", "trace", "odd")) if args.ext_tcp is None else bool(args.ext_tcp)
+    ext_tcp = (args.workload in ("imix", "trace", "odd", "tcptrack")) if args.ext_tcp is None else bool(args.ext_tcp)
     ifc = unet_amd.Iface(ext_tcp=ext_tcp)
     ctx = unet_amd.Offload(local)
     # A dedicated torch stream: its raw handle goes to the C ABI, so the kernels, torch's own ops and the
@@ -495,10 +514,10 @@ def main():
     # rotated over several distinct batches (consecutive index ranges of the same trace) so that no
     # launch finds its input in cache.
     rotate = args.rotate if args.rotate else (6 if kind == unet_amd.SYNTH_IPV4_HDR20 else 1)
-    op = args.workload if args.workload in ("csum", "generate", "fields", "txbuild", "eth1514", "tximix") else "verify"
+    op = args.workload if args.workload in ("csum", "generate", "fields", "txbuild", "eth1514", "tximix", "tcptrack") else "verify"
     batches = [Batch(ctx, stream, kind, ifc, r * n_global, n_global, shard_world, shard_rank, stride16, op) for r in range(rotate)]
     b0 = batches[0]
-    kernel = {"csum": "k_csum", "generate": "k_generate", "fields": "k_generate<read only>", "txbuild": "k_tx_build<MODE_L3>", "tximix": "k_tx_build<MODE_L3>", "eth1514": "k_verify<MODE_L2>"}.get(op, "k_ipv4_validate_rows" if kind == unet_amd.SYNTH_IPV4_HDR20 else "k_verify<MODE_L3>")
+    kernel = {"tcptrack": "k_verify<MODE_L3> + k_tcp_keys + DeviceRadixSort + k_tcp_apply + k_tcp_apply_long", "csum": "k_csum", "generate": "k_generate", "fields": "k_generate<read only>", "txbuild": "k_tx_build<MODE_L3>", "tximix": "k_tx_build<MODE_L3>", "eth1514": "k_verify<MODE_L2>"}.get(op, "k_ipv4_validate_rows" if kind == unet_amd.SYNTH_IPV4_HDR20 else "k_verify<MODE_L3>")
     torch.cuda.synchronize()
 
     # ---- timed region
@@ -563,6 +582,14 @@ def main():
         parity = bool(local_cnt[Verdict.DROP_L2_ETHERTYPE] == bad_type.sum() and local_cnt[Verdict.DROP_L2_NOT_FOR_ME] == bad_mac.sum()
                       and local_cnt[Verdict.DROP_UDP_CSUM] == bad_sum.sum()
                       and local_cnt[Verdict.ACCEPT_UDP] == b0.n - bad_type.sum() - bad_mac.sum() - bad_sum.sum())
+    tcp_extra = None
+    if op == "tcptrack":
+        st = b0.seg_state.cpu().numpy()
+        tcp_extra = {"segment_states": {k: int((st == v).sum()) for k, v in (("not_tcp", 0), ("new", 1), ("in_order", 2), ("out_of_order", 3), ("after_close", 4))},
+                     "longest_run_on_one_slot": int(b0.tcp_stats[0].item()), "runs_over_64": int(b0.tcp_stats[1].item()) // (args.steps + args.warmup),
+                     "table_slots": b0.table_slots, "workspace_bytes": b0.ws_bytes,
+                     "note": "the table carries over from step to step, as it would from batch to batch; tracking is an extension with no reference counterpart"}
+        parity = bool(tcp_extra["segment_states"]["not_tcp"] == b0.n - int(local_cnt[Verdict.ACCEPT_TCP]))
     if args.workload == "udp1500":
         # per-index fault rules of the trace: idx % 256 == 33 -> length mismatch; idx % 64 == 7 or
         # idx % 256 == 97 -> checksum failure (a zeroed field can verify only if the true value was 0)
@@ -655,6 +682,7 @@ def main():
             "hbm_GBps_all_gpus": sum(all_bytes) / rotate * args.steps / wall / 1e9,
             "verdict_counts": {Verdict(i).name: int(c) for i, c in enumerate(cnt) if c},
             "parity_check": parity,
+            **({"tcp_tracking": tcp_extra} if tcp_extra else {}),
         }
     ctx.close()
     if dist:

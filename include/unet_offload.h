@@ -188,6 +188,15 @@ int unet_verify_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_
 int unet_verify(unet_ctx* ctx, const uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16,
                 uint32_t stride16, const uint32_t* len, uint32_t n, const unet_iface* iface,
                 unet_result* out);
+/* The same verdicts for n records of ONE length laid out at a BYTE stride: record i occupies bytes
+ * [i * stride_bytes, i * stride_bytes + len) of d_buf (16-byte aligned; readable up to the end of the 16-byte chunk
+ * the last record ends in).  No slots, no tables: what a capture ring of fixed-size cells or a batch of
+ * minimum-size frames looks like -- 46-byte L3 packets and 60-byte frames are the shortest the reference's devices
+ * carry (src/devices/ethernet.rs:9-13), 74 bytes the shortest frame its tap driver sends (src/driver/tap.rs:147-152).
+ * len <= stride_bytes <= 256 (UNET_E_RANGE beyond: use unet_verify_dev, whose 16-byte pad weighs little there).
+ * Same functions and order of checks as unet_verify_dev, bit-identical results. */
+int unet_verify_bytes_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t buf_bytes, uint32_t stride_bytes,
+                          uint32_t len, uint32_t n, const unet_iface* iface, unet_result* d_out);
 
 /* The drain loop's way of using the GPU without threads of its own (src/protocols.rs:83-97 runs on the stack's
  * main thread): unet_verify_async stages batch k and returns while the GPU works on it, the caller packs batch
@@ -367,12 +376,31 @@ typedef struct unet_tcp_flow {   /* one table slot, 32 bytes; all zero = free */
 /* Applies the records of a batch to the table IN RECORD ORDER per flow (record i before record j > i) and writes
  * each record's outcome to d_seg_state[i].  d_results are the verdicts unet_verify_dev wrote for the same batch
  * (same iface mode).  table_slots must be a power of two (1 .. 2^30); the caller zeroes a new table.  The
- * library's own workspace (about 40 bytes per record) grows on demand, so this call may allocate; it is
+ * library's own workspace (about 45 bytes per record) grows on demand, so this call may allocate, and a
+ * reallocation waits for the device (unet_tcp_track_ws_dev below takes the caller's workspace instead); it is
  * enqueued on `stream` like every *_dev call. */
 int unet_tcp_track_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_t arena_bytes,
                        const uint32_t* d_off16, uint32_t stride16, const uint32_t* d_len,
                        const unet_result* d_results, uint32_t n, const unet_iface* iface,
                        unet_tcp_flow* d_table, uint32_t table_slots, uint8_t* d_seg_state);
+/* The same with the workspace in the caller's hands, so that the call itself never allocates or frees (a reallocation
+ * of the library's own buffer waits for the whole device): unet_tcp_track_workspace says how many bytes n records
+ * need (about 45 per record; host code), d_workspace is device memory of at least that size on a 256-byte boundary.
+ * d_stats (may be NULL; the caller zeroes it) receives how the batch fell onto the table: the walk over the
+ * segments of one table slot is sequential by definition, so one hot flow -- or a table far too small -- bounds the
+ * call.  Runs of more than 64 segments are walked by a whole wavefront that gathers them into LDS 64 at a time (no
+ * step of the walk waits for memory: about 20 ns per segment instead of a microsecond); longest_run tells the caller
+ * when to split its batches or grow its table. */
+typedef struct unet_tcp_stats {
+    uint32_t longest_run;  /* most segments that met one table slot in one call (maximum over the calls since it was zeroed) */
+    uint32_t long_runs;    /* runs of more than 64 segments (sum over those calls) */
+} unet_tcp_stats;
+int unet_tcp_track_workspace(uint32_t n, uint32_t table_slots, uint64_t* bytes);
+int unet_tcp_track_ws_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_t arena_bytes,
+                          const uint32_t* d_off16, uint32_t stride16, const uint32_t* d_len,
+                          const unet_result* d_results, uint32_t n, const unet_iface* iface,
+                          unet_tcp_flow* d_table, uint32_t table_slots, uint8_t* d_seg_state,
+                          void* d_workspace, uint64_t workspace_bytes, unet_tcp_stats* d_stats);
 /* Table slot a flow uses: a mix of unet_flow_hash5(src, dst, 6, sport, dport) independent of the bits that chose
  * the GPU.  Host code. */
 uint32_t unet_tcp_slot(uint32_t src, uint32_t dst, uint16_t sport, uint16_t dport, uint32_t table_slots);

@@ -14,7 +14,7 @@ HEADER = os.path.join(ROOT, "include", "unet_offload.h")
 
 C2RUST = {"uint8_t": "u8", "uint16_t": "u16", "uint32_t": "u32", "uint64_t": "u64"}
 NAMES = {"unet_result": "UnetResult", "unet_iface": "UnetIface", "unet_tx_desc": "UnetTxDesc", "unet_tx_fields": "UnetTxFields",
-         "unet_pcap_info": "UnetPcapInfo", "unet_ticket": "UnetTicket", "unet_tcp_flow": "UnetTcpFlow"}
+         "unet_pcap_info": "UnetPcapInfo", "unet_ticket": "UnetTicket", "unet_tcp_flow": "UnetTcpFlow", "unet_tcp_stats": "UnetTcpStats"}
 
 
 def c_structs():

@@ -158,6 +158,65 @@ def test_trace_chunk_tracks_like_the_oracle(offload):
     assert (exp_st != 0).sum() > n // 2
 
 
+def test_callers_workspace_long_runs_and_stats(offload):
+    """unet_tcp_track_ws_dev: the workspace is the caller's (nothing is allocated by the call), one hot flow puts
+    3,000 segments onto one table slot -- walked by a whole wave out of LDS -- between 4,000 segments of 500 other
+    flows, and the stats say how the batch fell onto the table.  Two calls in a row reuse workspace and table."""
+    import torch
+    rng = np.random.default_rng(77)
+    ifc = unet_amd.Iface(ext_tcp=True)
+    hot = dict(src=0x0A010203, sport=4444, dport=443, seq=1000)
+    others = [dict(src=int(rng.integers(1, 2**32 - 1)), sport=int(rng.integers(1, 65536)), dport=80, seq=int(rng.integers(0, 2**32))) for _ in range(500)]
+    slots = 1 << 12
+    table = np.zeros(slots, dtype=_ffi.TCP_FLOW_DTYPE)
+    d_tab = torch.from_numpy(table.view(np.uint8).reshape(-1).copy()).cuda()
+    n_max = 8000
+    need = _ffi.tcp_track_workspace(n_max, slots)
+    assert 30 * n_max < need < 80 * n_max + (1 << 20)
+    d_ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
+    assert d_ws.data_ptr() % 256 == 0
+    for call in range(2):
+        frames, who = [], []
+        for k in range(7000 if call == 0 else 3500):
+            f = hot if k % 7 < 3 else others[int(rng.integers(0, len(others)))]
+            payload = rng.integers(0, 256, size=int(rng.integers(0, 200)), dtype=np.uint8).tobytes()
+            seq = f["seq"] + (400 if rng.random() < 0.03 else 0)   # now and then a gap
+            frames.append(tcp_packet(f["src"], f["sport"], f["dport"], seq, ACK | PSH, payload))
+            f["seq"] = seq + len(payload)
+            who.append(f is hot)
+        n = len(frames)
+        arena, off16, lens = unet_amd.pack_arena(frames)
+        d_arena = torch.from_numpy(arena).cuda()
+        d_off = torch.from_numpy(off16.view(np.int32)).cuda()
+        d_len = torch.from_numpy(lens.view(np.int32)).cuda()
+        d_res = torch.zeros(n, dtype=torch.int32, device="cuda")
+        d_st = torch.full((n,), 0xEE, dtype=torch.uint8, device="cuda")
+        d_stats = torch.zeros(2, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        offload.verify_dev(d_arena.data_ptr(), arena.nbytes, d_off.data_ptr(), 0, d_len.data_ptr(), n, ifc, d_res.data_ptr())
+        offload.tcp_track_ws_dev(d_arena.data_ptr(), arena.nbytes, d_off.data_ptr(), 0, d_len.data_ptr(), d_res.data_ptr(), n, ifc, d_tab.data_ptr(),
+                                 slots, d_st.data_ptr(), d_ws.data_ptr(), need, d_stats.data_ptr())
+        offload.sync()
+        exp_res = O.recv_batch(arena, off16, lens, ifc)
+        assert np.array_equal(d_res.cpu().numpy().view(unet_amd.RESULT_DTYPE), exp_res)
+        exp_st = O.tcp_track(arena, off16, lens, exp_res, ifc, table)     # the oracle advances `table` in place
+        assert np.array_equal(d_st.cpu().numpy(), exp_st)
+        assert np.array_equal(d_tab.cpu().numpy(), table.view(np.uint8).reshape(-1))
+        # every record here is an accepted TCP segment: the hot flow's slot sees all of its segments (and any other
+        # flow that shares the slot), no other slot comes near
+        longest, long_runs = (int(x) for x in d_stats.cpu().numpy())
+        assert sum(who) <= longest <= sum(who) + 200 and 1 <= long_runs <= 3
+    # a workspace that is too small or misaligned is refused before anything is queued
+    with pytest.raises(_ffi.UnetError) as e:
+        offload.tcp_track_ws_dev(d_arena.data_ptr(), arena.nbytes, d_off.data_ptr(), 0, d_len.data_ptr(), d_res.data_ptr(), n, ifc, d_tab.data_ptr(),
+                                 slots, d_st.data_ptr(), d_ws.data_ptr(), 1024, None)
+    assert e.value.code == -5 and "unet_tcp_track_workspace" in str(e.value)
+    with pytest.raises(_ffi.UnetError) as e:
+        offload.tcp_track_ws_dev(d_arena.data_ptr(), arena.nbytes, d_off.data_ptr(), 0, d_len.data_ptr(), d_res.data_ptr(), n, ifc, d_tab.data_ptr(),
+                                 slots, d_st.data_ptr(), d_ws.data_ptr() + 16, need - 16, None)
+    assert e.value.code == -1
+
+
 def test_bad_arguments(offload):
     ifc = unet_amd.Iface(ext_tcp=True)
     with pytest.raises(_ffi.UnetError) as e:

@@ -28,9 +28,14 @@ for L in sizes:
     d_out = torch.zeros(n, dtype=torch.int32, device="cuda")
     nbytes = n * slots * 16
     row = {"len": L, "records": n, "mode": "L2" if l2 else "L3"}
-    for name in ("verify", "csum"):
+    names = ("verify", "csum")
+    if os.environ.get("UNET_SWEEP_BYTES") and L <= 256:
+        names = ("verify", "csum", "verify_bytes")  # the same records at a byte stride of L: no slots, no tables
+    for name in names:
         def run():
-            if name == "verify":
+            if name == "verify_bytes":
+                ctx.verify_bytes_dev(buf.data_ptr(), (n * L + 15) // 16 * 16, L, L, n, ifc, d_out.data_ptr(), st.cuda_stream)
+            elif name == "verify":
                 ctx.verify_dev(buf.data_ptr(), nbytes, None, slots, d_len.data_ptr(), n, ifc, d_out.data_ptr(), st.cuda_stream)
             else:
                 ctx.csum_batch_dev(buf.data_ptr(), nbytes, None, slots, d_len.data_ptr(), None, n, d_out.data_ptr(), st.cuda_stream)
@@ -43,7 +48,8 @@ for L in sizes:
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
-        row[name + "_GBps"] = round(n * (L + 8) / ms / 1e6, 1)
+        # algorithmic bytes: the record, its 4-byte result and -- where the layout needs one -- its 4-byte length
+        row[name + "_GBps"] = round(n * (L + (4 if name == "verify_bytes" else 8)) / ms / 1e6, 1)
         row[name + "_Gpkt_s"] = round(n / ms / 1e6, 3)
     out.append(row)
     print(json.dumps(row), flush=True)

@@ -151,6 +151,7 @@ _SIGS = {
     "unet_ipv4_validate_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
     "unet_ipv4_validate": (C.c_int, [_vp, _u8p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
     "unet_verify_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
+    "unet_verify_bytes_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_IfaceC), _vp]),
     "unet_verify": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
     "unet_verify_async": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp, C.POINTER(C.c_uint32)]),
     "unet_wait": (C.c_int, [_vp, C.c_uint32]),
@@ -173,6 +174,9 @@ _SIGS = {
                                 _u32p, _u32p, _u8p]),
     "unet_count_verdicts_dev": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _u64p]),
     "unet_tcp_track_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, _vp, C.c_uint32, C.POINTER(_IfaceC), _vp, C.c_uint32, _u8p]),
+    "unet_tcp_track_workspace": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
+    "unet_tcp_track_ws_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, _vp, C.c_uint32, C.POINTER(_IfaceC), _vp, C.c_uint32, _u8p,
+                                        _vp, C.c_uint64, _vp]),
     "unet_tcp_slot": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint16, C.c_uint16, C.c_uint32]),
     "unet_flow_hash5": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint16, C.c_uint16]),
     "unet_flow_hash_record": (C.c_uint32, [C.c_char_p, C.c_size_t, C.c_int]),
@@ -378,6 +382,13 @@ def flow_hash_record(rec: bytes, mode: int = 0) -> int:
     return int(load_library().unet_flow_hash_record(rec, len(rec), mode))
 
 
+def tcp_track_workspace(n: int, table_slots: int) -> int:
+    """Bytes of device workspace unet_tcp_track_ws_dev needs for n records."""
+    need = C.c_uint64(0)
+    _check(load_library().unet_tcp_track_workspace(int(n), int(table_slots), C.byref(need)))
+    return int(need.value)
+
+
 def flow_hash5(src: int, dst: int, proto: int, sport: int, dport: int) -> int:
     return int(load_library().unet_flow_hash5(src, dst, proto, sport, dport))
 
@@ -532,6 +543,11 @@ class Offload:
         ic = iface.c()
         _check(self.lib.unet_verify_dev(self.h, stream, d_arena, arena_bytes, d_off16, stride16, d_len, n, C.byref(ic), d_out))
 
+    def verify_bytes_dev(self, d_buf, buf_bytes, stride_bytes, length, n, iface: Iface, d_out, stream=None):
+        """unet_verify_bytes_dev: n records of `length` bytes at a byte stride (no 16-byte slots, no tables)."""
+        ic = iface.c()
+        _check(self.lib.unet_verify_bytes_dev(self.h, stream, d_buf, buf_bytes, stride_bytes, length, n, C.byref(ic), d_out))
+
     def ipv4_validate_dev(self, d_hdrs, n, iface: Iface, d_out, stream=None):
         ic = iface.c()
         _check(self.lib.unet_ipv4_validate_dev(self.h, stream, d_hdrs, n, C.byref(ic), d_out))
@@ -560,6 +576,13 @@ class Offload:
         ic = iface.c()
         _check(self.lib.unet_tcp_track_dev(self.h, stream, d_arena, arena_bytes, d_off16, stride16, d_len, d_results, n, C.byref(ic), d_table,
                                            table_slots, d_seg_state))
+
+    def tcp_track_ws_dev(self, d_arena, arena_bytes, d_off16, stride16, d_len, d_results, n, iface: Iface, d_table, table_slots, d_seg_state,
+                         d_workspace, workspace_bytes, d_stats=None, stream=None):
+        """unet_tcp_track_ws_dev: the caller's workspace (tcp_track_workspace bytes, 256-byte aligned), optional stats."""
+        ic = iface.c()
+        _check(self.lib.unet_tcp_track_ws_dev(self.h, stream, d_arena, arena_bytes, d_off16, stride16, d_len, d_results, n, C.byref(ic), d_table,
+                                              table_slots, d_seg_state, d_workspace, workspace_bytes, d_stats))
 
     def flow_hash_dev(self, d_arena, arena_bytes, d_off16, stride16, d_len, n, iface: Iface, d_hash, stream=None):
         ic = iface.c()

@@ -953,6 +953,81 @@ __global__ __launch_bounds__(kBlock, (TILE == 64 ? UNET_OCC64 : 6) * (256 / UNET
     if (t.lane < t.cnt) out[t.first + t.lane] = res;
 }
 
+// ------------------------------------------- the same verdicts for records of ONE length at a BYTE stride
+// Records of `len` bytes, record i at byte i * stride of the buffer (stride >= len, both at most kBytesMaxLen): no
+// 16-byte slots, no tables.  A record of 65 bytes costs 80 bytes of arena and 8 bytes of tables in the slot layout
+// (1.35 x its own bytes); here it costs 65.  A wave takes the byte range of its records (at most 4 KiB, starting
+// on a 128-byte line) into LDS with whole streaming 1 KiB rows, all requested up front; every lane then reads its
+// own record out of LDS at its byte offset -- the LDS serves 4- and 16-byte reads at any byte address -- so sums and
+// header fields are taken in the record's own alignment and the rest is the code of the slot kernels.
+constexpr u32 kBytesMaxLen = 256;   // longest record (and stride)
+constexpr u32 kBytesStage = 4096;   // record bytes one wave stages
+constexpr u32 kBytesArea = (127u + kBytesStage + 16u + 15u) / 16u + 1u;  // chunks: lead, records, one chunk of read-ahead
+constexpr u32 kBytesRows = (kBytesArea + kWave - 1u) / kWave;            // 5
+
+// Dword k / chunk k of a record that starts at any byte address of LDS.
+struct LdsBytesFetch {
+    const uint8_t* p;
+    __device__ __forceinline__ u32 operator()(u32 k) const {
+        u32 v;
+        __builtin_memcpy(&v, p + 4u * k, 4);
+        return v;
+    }
+    __device__ __forceinline__ u32x4 chunk(u32 k) const {
+        u32x4 v;
+        __builtin_memcpy(&v, p + 16u * k, 16);
+        return v;
+    }
+};
+
+// Records one wave takes: as many as fit its 4 KiB, whatever their number -- a lane works through records lane,
+// lane + 64, ... of the wave's group (twenty-byte records: 204 to a wave, four to a lane at most).  Short records
+// are latency-bound: what a wave has in flight is what counts, so it always asks for its whole 4 KiB at once.
+__host__ __device__ inline u32 bytes_per_wave(u32 stride) { return stride == 0u ? 0u : kBytesStage / stride; }
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock, 8) void k_verify_bytes(const uint8_t* __restrict__ buf, u32 stride, u32 len, u32 n, IfaceDev ifc,
+                                                            u32* __restrict__ out) {
+    __shared__ u32x4 lds[(kBlock / kWave) * kBytesArea];
+    const u32 lane = threadIdx.x & 63u;
+    u32x4* area = lds + (threadIdx.x >> 6) * kBytesArea;
+    const u32 per = bytes_per_wave(stride);
+    const u64 first = ((u64)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * per;
+    if (first >= n) return;
+    const u32 cnt = n - first < per ? (u32)(n - first) : per;
+    const u64 b0 = first * stride;
+    const u64 base = b0 & ~127ull;
+    const u32 lead = (u32)(b0 - base);
+    // chunks that hold bytes of these records (the host has checked that the buffer is readable that far)
+    const u32 span = (lead + (cnt - 1u) * stride + len + 15u) >> 4;
+    const u32x4* p = reinterpret_cast<const u32x4*>(buf) + (base >> 4);
+    u32x4 r[kBytesRows];
+#pragma unroll
+    for (u32 k = 0; k < kBytesRows; ++k) {
+        r[k] = u32x4{0, 0, 0, 0};
+        if (k * kWave < span) r[k] = ld_stream(p + min(k * kWave + lane, span - 1u));  // wave-uniform: only the rows that exist
+    }
+#pragma unroll
+    for (u32 k = 0; k < kBytesRows; ++k)
+        if (k * kWave + lane < span) area[k * kWave + lane] = r[k];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const u32 nfull = len >> 4;
+    const LaneTail tail(len);
+#pragma nounroll
+    for (u32 i = lane; i < cnt; i += kWave) {
+        const LdsBytesFetch f{reinterpret_cast<const uint8_t*>(area) + lead + i * stride};
+        u32 total = 0;
+#pragma unroll
+        for (u32 k = 0; k < kBytesMaxLen / 16u; ++k) {
+            if (k < nfull) total = sum_chunk(f.chunk(k), total);  // (wave-uniform: every record has the same length)
+        }
+        if ((len & 15u) != 0u) total = sum_chunk(tail.apply(f.chunk(nfull)), total);
+        const Parsed P = parse_record<MODE>(f, f, len, ifc);
+        out[first + i] = P.kind == K_DONE ? P.res : finalize_record(P, total);
+    }
+}
+
 // ------------------------------------ a2-a4: Ipv4Header::try_from + validate, bare headers
 // 20-byte records back to back.  Four headers are 80 bytes = five aligned 16-byte chunks, so a lane
 // owns G groups of four headers: 5*G dwordx4 loads, all issued before the first use (the wave's
@@ -1697,10 +1772,12 @@ __global__ __launch_bounds__(kBlock) void k_stream_read(const u32x4* __restrict_
     if ((threadIdx.x & 63u) == 0u) atomicAdd(&sink[blockIdx.x & 4095u], acc);
 }
 
-// The same bytes read the way the record kernels read them: short-lived waves, each owning one contiguous piece of
-// kPieceChunks chunks (24 KiB, what a wave of k_verify covers on 1500-byte records), two non-temporal 1 KiB rows
-// requested ahead of the pair being summed.  On some boxes this shape reads faster than the slabs above; the
-// benchmark reports the better of the two as what a pure read of the buffer attains.
+// The same bytes read by short-lived waves, each owning one contiguous piece of kPieceChunks chunks (24 KiB, what a
+// wave of k_verify covers on 1500-byte records), four non-temporal 1 KiB rows requested ahead of the four being
+// summed, and -- the launch adds unused LDS to every workgroup -- at most three workgroups resident on a CU: the
+// fastest pure read found on MI355X (7.1 TB/s on pseudo-random bytes; eight resident workgroups 6.9-7.0, the slabs
+// above 6.7-6.8; a buffer of one repeated byte reads 5 % faster than pseudo-random bytes).  The benchmark reports
+// the better of the two shapes as what a pure read of its buffer attains.
 constexpr u32 kPieceChunks = 1536;
 __global__ __launch_bounds__(kBlock) void k_stream_read_pieces(const u32x4* __restrict__ buf, u64 nchunks, u32* __restrict__ sink) {
     const u32 lane = threadIdx.x & 63u;
@@ -1712,16 +1789,21 @@ __global__ __launch_bounds__(kBlock) void k_stream_read_pieces(const u32x4* __re
     const u32x4* p = buf + lo;
     const u32 last = n - 1u;
     u32 acc = 0;
-    // (the second row of a pair with the default policy: the pair the record kernels use, and 1 % faster than two
-    // streaming rows in the probe of that pattern)
-    u32x4 a = ld_stream(p + min(lane, last)), b = p[min(lane + kWave, last)];
-    for (u32 c = 2u * kWave; c < n + 2u * kWave; c += 2u * kWave) {
+    u32x4 v0 = ld_stream(p + min(lane, last)), v1 = ld_stream(p + min(lane + kWave, last));
+    u32x4 v2 = ld_stream(p + min(lane + 2u * kWave, last)), v3 = ld_stream(p + min(lane + 3u * kWave, last));
+    for (u32 c = 4u * kWave; c < n + 4u * kWave; c += 4u * kWave) {
         // rows past the piece's end re-read its last chunk (same line, no traffic) and are not summed
-        const u32x4 na = ld_stream(p + min(c + lane, last)), nb = p[min(c + lane + kWave, last)];
-        acc = sum_chunk(zero_unless(a, c - 2u * kWave + lane < n), acc);
-        acc = sum_chunk(zero_unless(b, c - kWave + lane < n), acc);
-        a = na;
-        b = nb;
+        const u32x4 n0 = ld_stream(p + min(c + lane, last)), n1 = ld_stream(p + min(c + lane + kWave, last));
+        const u32x4 n2 = ld_stream(p + min(c + lane + 2u * kWave, last)), n3 = ld_stream(p + min(c + lane + 3u * kWave, last));
+        const u32 at = c - 4u * kWave + lane;
+        acc = sum_chunk(zero_unless(v0, at < n), acc);
+        acc = sum_chunk(zero_unless(v1, at + kWave < n), acc);
+        acc = sum_chunk(zero_unless(v2, at + 2u * kWave < n), acc);
+        acc = sum_chunk(zero_unless(v3, at + 3u * kWave < n), acc);
+        v0 = n0;
+        v1 = n1;
+        v2 = n2;
+        v3 = n3;
     }
     acc = wave_sum(acc);
     if (lane == 0u) atomicAdd(&sink[wave & 4095u], acc);

@@ -117,20 +117,83 @@ __global__ __launch_bounds__(kBlock) void k_tcp_keys(Batch b, const u32* __restr
     keys[i] = key;
 }
 
-// (3) one lane per sorted position; the lane at the start of a slot's run walks the run
+// Counters one call leaves behind (mirrors unet_tcp_stats).
+struct TcpStats {
+    u32 longest_run;  // most segments that met one table slot in this batch
+    u32 long_runs;    // runs longer than kTcpShortRun (each walked by a whole wave out of LDS)
+};
+constexpr u32 kTcpShortRun = 64;  // runs up to this length are walked by the lane that finds their start
+
+// (3) one lane per sorted position; the lane at the start of a slot's run finds the run's end (the keys are sorted:
+// a binary search) and walks the run if it is short.  A long run -- a hot flow, or a table far too small for the
+// batch -- would hold one lane on a chain of dependent loads for as long as it lasts: it goes onto a list instead.
 __global__ __launch_bounds__(kBlock) void k_tcp_apply(const u32* __restrict__ keys, const u32* __restrict__ idx, const TcpSeg* __restrict__ segs,
-                                                      u32 n, u32 log2_slots, TcpFlow* __restrict__ table, uint8_t* __restrict__ seg_state) {
+                                                      u32 n, u32 log2_slots, TcpFlow* __restrict__ table, uint8_t* __restrict__ seg_state,
+                                                      u32* __restrict__ long_list, u32* __restrict__ long_count, TcpStats* __restrict__ stats) {
     const u32 p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= n) return;
     const u32 key = keys[p];
     if (key >= (1u << log2_slots)) return;
     if (p > 0u && keys[p - 1u] == key) return;
+    // first position behind the run: the first q in (p, n] with keys[q] != key (keys[n] counts as different)
+    u32 lo = p + 1u, hi = n;
+    if (lo < n && keys[lo] == key) {
+        while (lo < hi) {
+            const u32 mid = lo + ((hi - lo) >> 1);
+            if (keys[mid] == key) lo = mid + 1u; else hi = mid;
+        }
+    }
+    const u32 end = lo < n && keys[lo] == key ? n : lo;
+    const u32 run = end - p;
+    if (stats) atomicMax(&stats->longest_run, run);
+    if (run > kTcpShortRun) {
+        const u32 at = atomicAdd(long_count, 1u);
+        long_list[2u * at] = p;
+        long_list[2u * at + 1u] = run;
+        if (stats) atomicAdd(&stats->long_runs, 1u);
+        return;
+    }
     TcpFlow f = table[key];
-    for (u32 q = p; q < n && keys[q] == key; ++q) {
+    for (u32 q = p; q < end; ++q) {
         const u32 i = idx[q];
         seg_state[i] = (uint8_t)tcp_apply(f, segs[i]);
     }
     table[key] = f;
+}
+
+// (3b) the long runs, one wave each (the waves share the list out between them): 64 segments at a time are gathered
+// into LDS by the whole wave, lane 0 runs the state machine over them out of LDS, and the wave stores the 64
+// outcomes.  The walk stays sequential -- it is the definition -- but no step of it waits for memory.
+__global__ __launch_bounds__(kBlock) void k_tcp_apply_long(const u32* __restrict__ keys, const u32* __restrict__ idx, const TcpSeg* __restrict__ segs,
+                                                           TcpFlow* __restrict__ table, uint8_t* __restrict__ seg_state,
+                                                           const u32* __restrict__ long_list, const u32* __restrict__ long_count) {
+    __shared__ TcpSeg seg_lds[kBlock / kWave][kWave];
+    __shared__ u32 out_lds[kBlock / kWave][kWave];
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const u32 waves = gridDim.x * (kBlock / kWave);
+    const u32 count = *long_count;
+    for (u32 r = blockIdx.x * (kBlock / kWave) + w; r < count; r += waves) {
+        const u32 p = long_list[2u * r], run = long_list[2u * r + 1u];
+        const u32 key = keys[p];
+        TcpFlow f = table[key];  // (every lane holds a copy; lane 0's is the one that advances)
+        for (u32 at = 0; at < run; at += kWave) {
+            const u32 m = run - at < kWave ? run - at : kWave;
+            u32 i = 0;
+            if (lane < m) {
+                i = idx[p + at + lane];
+                seg_lds[w][lane] = segs[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0u) {
+                for (u32 k = 0; k < m; ++k) out_lds[w][k] = tcp_apply(f, seg_lds[w][k]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < m) seg_state[i] = (uint8_t)out_lds[w][lane];
+        }
+        if (lane == 0u) table[key] = f;
+    }
 }
 
 }  // namespace unetdev

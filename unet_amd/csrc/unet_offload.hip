@@ -37,6 +37,7 @@ static_assert(sizeof(unet_tx_fields) == 4 && offsetof(unet_tx_fields, l4_csum) =
 static_assert(sizeof(unet_pcap_info) == 48 && offsetof(unet_pcap_info, nanosecond) == 28 && offsetof(unet_pcap_info, arena_bytes) == 32 &&
               offsetof(unet_pcap_info, trailing_bytes) == 40, "unet_pcap_info layout");
 static_assert(sizeof(unet_ticket) == 4, "unet_ticket layout");
+static_assert(sizeof(unet_tcp_stats) == 8, "unet_tcp_stats layout");
 static_assert(sizeof(unet_tcp_flow) == 32 && offsetof(unet_tcp_flow, next_seq) == 12 && offsetof(unet_tcp_flow, after_close) == 28, "unet_tcp_flow layout");
 static_assert((int)UNET_V_COUNT == (int)V_COUNT, "verdict tables out of sync");
 static_assert((int)UNET_V_L3_HEADER_OK == (int)V_L3_HEADER_OK, "verdict tables out of sync");
@@ -198,6 +199,7 @@ struct unet_ctx {
     int tx_tile_override = 0;     // UNET_TX_TILE (1, 2, 4, 8, 16, 32, 64), read once at unet_open
     int tile_once = 0;            // records per wave for the launch a host-pointer entry point is about to make
     bool hdr_plain = false;       // UNET_HDR_PLAIN, read once at unet_open
+    u32 lds_pad = 0;              // UNET_LDS_PAD: bytes of unused LDS added to every workgroup of the record kernels (experiments: fewer resident workgroups)
     u32 mean_len_hint = 0;        // unet_hint_mean_len
     bool len_known = false;       // set by the host-pointer entry points around their *_dev call
     u32 mean_len_known = 0, max_len_known = 0;
@@ -420,7 +422,7 @@ inline void count_on_host(unet_ctx* c, const u32* res, u32 n) {
     }
 }
 
-int launch_verify(hipStream_t s, const Batch& b_in, const unet_iface* iface, int records_per_wave, u32* d_out) {
+int launch_verify(hipStream_t s, const Batch& b_in, const unet_iface* iface, int records_per_wave, u32* d_out, u32 lds_pad = 0) {
     const IfaceDev ifc = to_dev(iface);
     Batch b = b_in;
     b.tile_n = (u32)records_per_wave;
@@ -428,7 +430,7 @@ int launch_verify(hipStream_t s, const Batch& b_in, const unet_iface* iface, int
     if (int rc = check_tiles(n, (u32)records_per_wave)) return rc;
     const int tile = kernel_tile(records_per_wave);
 #define UNET_LAUNCH_VERIFY(M, T) \
-    hipLaunchKernelGGL((k_verify<M, T>), dim3(tiles_grid(n, (u32)records_per_wave)), dim3(kBlock), 0, s, b, ifc, d_out)
+    hipLaunchKernelGGL((k_verify<M, T>), dim3(tiles_grid(n, (u32)records_per_wave)), dim3(kBlock), lds_pad, s, b, ifc, d_out)
     if (iface->mode == UNET_MODE_L2) {
         if (tile == 16) UNET_LAUNCH_VERIFY(MODE_L2, 16);
         else if (tile == 32) UNET_LAUNCH_VERIFY(MODE_L2, 32);
@@ -584,6 +586,7 @@ int unet_open(int device_id, unet_ctx** out_ctx) {
         c->tile_override = v < 1 ? 1 : (v > 64 ? 64 : v);  // records per wave, any value from 1 to 64
     }
     c->hdr_plain = getenv("UNET_HDR_PLAIN") != nullptr;
+    if (const char* t = getenv("UNET_LDS_PAD")) c->lds_pad = (u32)strtoul(t, nullptr, 10);
     if (const char* z = getenv("UNET_ZERO_COPY_BYTES")) c->zero_copy_bytes = strtoull(z, nullptr, 10);
     if (const char* t = getenv("UNET_TX_TILE")) {
         const int v = atoi(t);
@@ -820,7 +823,35 @@ int unet_verify_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_
     HIP_TRY(hipSetDevice(ctx->device));
     Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
     if (arena_too_small(arena_bytes)) return fail(UNET_E_INVAL, "arena must hold at least 16 bytes");
-    return launch_verify(pick(ctx, stream), b, iface, pick_tile(ctx, arena_bytes, stride16, n), (u32*)d_out);
+    return launch_verify(pick(ctx, stream), b, iface, pick_tile(ctx, arena_bytes, stride16, n), (u32*)d_out, ctx->lds_pad);
+}
+
+int unet_verify_bytes_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t buf_bytes, uint32_t stride_bytes,
+                          uint32_t len, uint32_t n, const unet_iface* iface, unet_result* d_out) {
+    if (!ctx) return fail(UNET_E_INVAL, "null context");
+    if (n == 0) return UNET_OK;
+    if (!d_buf || !iface || !d_out) return fail(UNET_E_INVAL, "null argument");
+    if (((uintptr_t)d_buf & 15u) != 0) return fail(UNET_E_INVAL, "buffer must be 16-byte aligned");
+    if (iface->mode != UNET_MODE_L3 && iface->mode != UNET_MODE_L2) return fail(UNET_E_INVAL, "bad iface mode %d", iface->mode);
+    if (stride_bytes == 0 || stride_bytes > kBytesMaxLen || len > stride_bytes)
+        return fail(UNET_E_RANGE, "byte-stride records: need len <= stride <= %u, got len %u, stride %u (longer records: unet_verify_dev)", kBytesMaxLen, len,
+                    stride_bytes);
+    // the records are read in 16-byte chunks: the buffer must reach the end of the chunk the last record ends in
+    const u64 need = (((u64)(n - 1u) * stride_bytes + len) + 15u) & ~15ull;
+    if (need > buf_bytes || buf_bytes < 16)
+        return fail(UNET_E_RANGE, "%u records of %u bytes at stride %u end at byte %llu (in whole 16-byte chunks), the buffer has %llu", n, len, stride_bytes,
+                    (unsigned long long)need, (unsigned long long)buf_bytes);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const u32 per = bytes_per_wave(stride_bytes);
+    int rc;
+    if ((rc = check_tiles(n, per))) return rc;
+    const IfaceDev ifc = to_dev(iface);
+    if (iface->mode == UNET_MODE_L2)
+        hipLaunchKernelGGL(k_verify_bytes<MODE_L2>, dim3(tiles_grid(n, per)), dim3(kBlock), 0, pick(ctx, stream), d_buf, stride_bytes, len, n, ifc, (u32*)d_out);
+    else
+        hipLaunchKernelGGL(k_verify_bytes<MODE_L3>, dim3(tiles_grid(n, per)), dim3(kBlock), 0, pick(ctx, stream), d_buf, stride_bytes, len, n, ifc, (u32*)d_out);
+    HIP_TRY(hipGetLastError());
+    return UNET_OK;
 }
 
 int unet_verify(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16, uint32_t stride16,
@@ -1150,7 +1181,7 @@ int unet_tx_build_opts_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload
     Batch b{d_payload_arena, payload_arena_bytes, d_payload_off16, payload_stride16, d_payload_len, n};
     const IfaceDev ifc = to_dev(iface);
 #define UNET_TX_LAUNCH(M, T)                                                                                             \
-    hipLaunchKernelGGL((k_tx_build<M, T>), dim3(tiles_grid(n, b.tile_n)), dim3(kBlock), 0, pick(ctx, stream), b, (const TxDesc*)d_desc, ifc, \
+    hipLaunchKernelGGL((k_tx_build<M, T>), dim3(tiles_grid(n, b.tile_n)), dim3(kBlock), ctx->lds_pad, pick(ctx, stream), b, (const TxDesc*)d_desc, ifc, \
                        d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status, flags)
     int tile = tx_tile_for(pick_mean(ctx, payload_arena_bytes, payload_stride16, n));
     if (ctx->tx_tile_override) tile = ctx->tx_tile_override;
@@ -1339,28 +1370,64 @@ uint32_t unet_tcp_slot(uint32_t src, uint32_t dst, uint16_t sport, uint16_t dpor
     return tcp_slot(flow_hash5(src, dst, 6u, sport, dport), (u32)l);
 }
 
-int unet_tcp_track_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_t arena_bytes, const uint32_t* d_off16,
-                       uint32_t stride16, const uint32_t* d_len, const unet_result* d_results, uint32_t n, const unet_iface* iface,
-                       unet_tcp_flow* d_table, uint32_t table_slots, uint8_t* d_seg_state) {
+namespace {
+// Workspace of one tracking call over n records: keys and indices in and out of the sort (4 x u32 per record), the
+// extracted segments, the list of long runs with its counter, the sort's own scratch.
+struct TcpWs {
+    size_t a4, aseg, alist, sort_bytes, total;
+};
+int tcp_workspace(u32 n, int l2s, TcpWs* w) {
+    w->sort_bytes = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, w->sort_bytes, (const u32*)nullptr, (u32*)nullptr, (const u32*)nullptr, (u32*)nullptr, (int)n, 0,
+                                               l2s + 1, (hipStream_t) nullptr));
+    w->a4 = ((size_t)n * 4u + 255u) & ~(size_t)255u;
+    w->aseg = ((size_t)n * sizeof(TcpSeg) + 255u) & ~(size_t)255u;
+    w->alist = (((size_t)n / kTcpShortRun + 1u) * 8u + 256u + 255u) & ~(size_t)255u;  // a long run holds more than kTcpShortRun records
+    w->total = 4u * w->a4 + w->aseg + w->alist + ((w->sort_bytes + 255u) & ~(size_t)255u) + 256u;
+    return UNET_OK;
+}
+}  // namespace
+
+int unet_tcp_track_workspace(uint32_t n, uint32_t table_slots, uint64_t* bytes) {
+    if (!bytes) return fail(UNET_E_INVAL, "null argument");
+    const int l2s = log2_exact(table_slots);
+    if (l2s < 0 || l2s > 30) return fail(UNET_E_INVAL, "table_slots must be a power of two up to 2^30, got %u", table_slots);
+    if (n > 0x7fffffffu) return fail(UNET_E_RANGE, "at most 2^31 - 1 records per call");
+    TcpWs w;
+    int rc = tcp_workspace(n ? n : 1u, l2s, &w);
+    if (rc) return rc;
+    *bytes = w.total;
+    return UNET_OK;
+}
+
+int unet_tcp_track_ws_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_t arena_bytes, const uint32_t* d_off16,
+                          uint32_t stride16, const uint32_t* d_len, const unet_result* d_results, uint32_t n, const unet_iface* iface,
+                          unet_tcp_flow* d_table, uint32_t table_slots, uint8_t* d_seg_state, void* d_workspace, uint64_t workspace_bytes,
+                          unet_tcp_stats* d_stats) {
+    static_assert(sizeof(unet_tcp_stats) == sizeof(TcpStats), "stats layout");
     int rc = check_batch(ctx, d_arena, d_off16, stride16, d_len, n);
     if (rc) return rc;
     if (n == 0) return UNET_OK;
-    if (!d_results || !iface || !d_table || !d_seg_state) return fail(UNET_E_INVAL, "null argument");
+    if (!d_results || !iface || !d_table || !d_seg_state || !d_workspace) return fail(UNET_E_INVAL, "null argument");
     if (iface->mode != UNET_MODE_L3 && iface->mode != UNET_MODE_L2) return fail(UNET_E_INVAL, "bad iface mode %d", iface->mode);
     const int l2s = log2_exact(table_slots);
     if (l2s < 0 || l2s > 30) return fail(UNET_E_INVAL, "table_slots must be a power of two up to 2^30, got %u", table_slots);
+    if (n > 0x7fffffffu) return fail(UNET_E_RANGE, "at most 2^31 - 1 records per call");
+    if (((uintptr_t)d_workspace & 255u) != 0) return fail(UNET_E_INVAL, "workspace must be 256-byte aligned");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = pick(ctx, stream);
-    // workspace: keys and indices (in and out of the sort), the extracted segments, the sort's own scratch
-    size_t sort_bytes = 0;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const u32*)nullptr, (u32*)nullptr, (const u32*)nullptr, (u32*)nullptr, (int)n, 0,
-                                               l2s + 1, s));
-    const size_t a4 = ((size_t)n * 4u + 255u) & ~(size_t)255u, aseg = ((size_t)n * sizeof(TcpSeg) + 255u) & ~(size_t)255u;
-    if ((rc = ensure(ctx, ctx->d_tcp, 4u * a4 + aseg + sort_bytes + 256u))) return rc;
-    uint8_t* w = (uint8_t*)ctx->d_tcp.p;
-    u32 *keys_in = (u32*)w, *keys_out = (u32*)(w + a4), *idx_in = (u32*)(w + 2u * a4), *idx_out = (u32*)(w + 3u * a4);
-    TcpSeg* segs = (TcpSeg*)(w + 4u * a4);
-    void* sort_tmp = w + 4u * a4 + aseg;
+    TcpWs ws;
+    if ((rc = tcp_workspace(n, l2s, &ws))) return rc;
+    if (workspace_bytes < ws.total)
+        return fail(UNET_E_RANGE, "workspace of %llu bytes, %u records need %llu (unet_tcp_track_workspace)", (unsigned long long)workspace_bytes, n,
+                    (unsigned long long)ws.total);
+    uint8_t* w = (uint8_t*)d_workspace;
+    u32 *keys_in = (u32*)w, *keys_out = (u32*)(w + ws.a4), *idx_in = (u32*)(w + 2u * ws.a4), *idx_out = (u32*)(w + 3u * ws.a4);
+    TcpSeg* segs = (TcpSeg*)(w + 4u * ws.a4);
+    u32* long_count = (u32*)(w + 4u * ws.a4 + ws.aseg);  // counter in the first 256 bytes, the list behind it
+    u32* long_list = long_count + 64;
+    void* sort_tmp = w + 4u * ws.a4 + ws.aseg + ws.alist;
+    HIP_TRY(hipMemsetAsync(long_count, 0, 256, s));
     Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
     const u32 grid = (n + kBlock - 1) / kBlock;
     if (iface->mode == UNET_MODE_L2)
@@ -1369,11 +1436,33 @@ int unet_tcp_track_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint
         hipLaunchKernelGGL(k_tcp_keys<MODE_L3>, dim3(grid), dim3(kBlock), 0, s, b, (const u32*)d_results, (u32)l2s, keys_in, idx_in, segs, d_seg_state);
     HIP_TRY(hipGetLastError());
     // radix sort is stable: records of one slot stay in index order
+    size_t sort_bytes = ws.sort_bytes;
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, (const u32*)keys_in, keys_out, (const u32*)idx_in, idx_out, (int)n, 0, l2s + 1, s));
     hipLaunchKernelGGL(k_tcp_apply, dim3(grid), dim3(kBlock), 0, s, (const u32*)keys_out, (const u32*)idx_out, (const TcpSeg*)segs, n, (u32)l2s,
-                       (TcpFlow*)d_table, d_seg_state);
+                       (TcpFlow*)d_table, d_seg_state, long_list, long_count, (TcpStats*)d_stats);
+    HIP_TRY(hipGetLastError());
+    // the long runs (their number is known on the device only: a fixed grid shares them out; with none, its waves end at once)
+    const u32 long_grid = grid < 1024u ? grid : 1024u;
+    hipLaunchKernelGGL(k_tcp_apply_long, dim3(long_grid), dim3(kBlock), 0, s, (const u32*)keys_out, (const u32*)idx_out, (const TcpSeg*)segs,
+                       (TcpFlow*)d_table, d_seg_state, (const u32*)long_list, (const u32*)long_count);
     HIP_TRY(hipGetLastError());
     return UNET_OK;
+}
+
+int unet_tcp_track_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_t arena_bytes, const uint32_t* d_off16,
+                       uint32_t stride16, const uint32_t* d_len, const unet_result* d_results, uint32_t n, const unet_iface* iface,
+                       unet_tcp_flow* d_table, uint32_t table_slots, uint8_t* d_seg_state) {
+    // the form that keeps its workspace in the context: it grows on demand, so this call may allocate (and a
+    // reallocation waits for the device); callers that cannot have that pass their own to unet_tcp_track_ws_dev
+    if (!ctx) return fail(UNET_E_INVAL, "null context");
+    if (n == 0) return UNET_OK;
+    uint64_t need = 0;
+    int rc = unet_tcp_track_workspace(n, table_slots, &need);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if ((rc = ensure(ctx, ctx->d_tcp, (size_t)need))) return rc;
+    return unet_tcp_track_ws_dev(ctx, stream, d_arena, arena_bytes, d_off16, stride16, d_len, d_results, n, iface, d_table, table_slots, d_seg_state,
+                                 ctx->d_tcp.p, ctx->d_tcp.cap, nullptr);
 }
 
 /* ---------------------------------------------------------------- flow hash */
@@ -1571,7 +1660,9 @@ int unet_stream_read_pieces_dev(unet_ctx* ctx, void* stream, const uint8_t* d_bu
     if (grid == 0) return UNET_OK;
     if (grid * kBlock >= (1ull << 32)) return fail(UNET_E_RANGE, "buffer of %llu bytes is too large for one launch", (unsigned long long)bytes);
     HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_stream_read_pieces, dim3((u32)grid), dim3(kBlock), 0, pick(ctx, stream), (const u32x4*)d_buf, nchunks, d_sink);
+    // unused LDS so that at most three workgroups share a CU's 160 KiB: fewer resident waves read faster (see the kernel)
+    constexpr u32 kPadLds = (160u << 10) / 3u - 1024u;
+    hipLaunchKernelGGL(k_stream_read_pieces, dim3((u32)grid), dim3(kBlock), kPadLds, pick(ctx, stream), (const u32x4*)d_buf, nchunks, d_sink);
     HIP_TRY(hipGetLastError());
     return UNET_OK;
 }
