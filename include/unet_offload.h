@@ -188,6 +188,18 @@ int unet_verify_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_
 int unet_verify(unet_ctx* ctx, const uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16,
                 uint32_t stride16, const uint32_t* len, uint32_t n, const unet_iface* iface,
                 unet_result* out);
+/* The same verdicts for a batch of a FEW LONG records, one wavefront per 4 KiB segment of a record instead of one per
+ * record or per several: sixteen jumbo frames (the loopback device carries up to 65535 bytes,
+ * src/devices/loopback.rs:16) keep 16 x 16 wavefronts busy instead of four.  max_len bounds the record lengths (a
+ * record that needs more 4 KiB segments than max_len does gets UNET_V_NONE -- pass the true maximum); d_workspace holds
+ * one u32 per segment (unet_verify_split_workspace bytes, 4-byte aligned; host code).  Results are bit-identical to
+ * unet_verify_dev: sums of 16-bit words add up over segments that start on even offsets.  unet_verify itself takes
+ * this path when a batch has fewer than 128 wavefronts' worth of records of 16 KiB and more. */
+int unet_verify_split_workspace(uint32_t n, uint32_t max_len, uint64_t* bytes);
+int unet_verify_split_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_t arena_bytes,
+                          const uint32_t* d_off16, uint32_t stride16, const uint32_t* d_len, uint32_t n,
+                          uint32_t max_len, const unet_iface* iface, unet_result* d_out, void* d_workspace,
+                          uint64_t workspace_bytes);
 /* The same verdicts for n records of ONE length laid out at a BYTE stride: record i occupies bytes
  * [i * stride_bytes, i * stride_bytes + len) of d_buf (16-byte aligned; readable up to the end of the 16-byte chunk
  * the last record ends in).  No slots, no tables: what a capture ring of fixed-size cells or a batch of

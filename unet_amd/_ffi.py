@@ -151,6 +151,9 @@ _SIGS = {
     "unet_ipv4_validate_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
     "unet_ipv4_validate": (C.c_int, [_vp, _u8p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
     "unet_verify_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
+    "unet_verify_split_workspace": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
+    "unet_verify_split_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.c_uint32, C.POINTER(_IfaceC), _vp, _vp,
+                                        C.c_uint64]),
     "unet_verify_bytes_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_IfaceC), _vp]),
     "unet_verify": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
     "unet_verify_async": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp, C.POINTER(C.c_uint32)]),
@@ -382,6 +385,12 @@ def flow_hash_record(rec: bytes, mode: int = 0) -> int:
     return int(load_library().unet_flow_hash_record(rec, len(rec), mode))
 
 
+def verify_split_workspace(n: int, max_len: int) -> int:
+    need = C.c_uint64(0)
+    _check(load_library().unet_verify_split_workspace(int(n), int(max_len), C.byref(need)))
+    return int(need.value)
+
+
 def tcp_track_workspace(n: int, table_slots: int) -> int:
     """Bytes of device workspace unet_tcp_track_ws_dev needs for n records."""
     need = C.c_uint64(0)
@@ -542,6 +551,13 @@ class Offload:
     def verify_dev(self, d_arena, arena_bytes, d_off16, stride16, d_len, n, iface: Iface, d_out, stream=None):
         ic = iface.c()
         _check(self.lib.unet_verify_dev(self.h, stream, d_arena, arena_bytes, d_off16, stride16, d_len, n, C.byref(ic), d_out))
+
+    def verify_split_dev(self, d_arena, arena_bytes, d_off16, stride16, d_len, n, max_len, iface: Iface, d_out, d_workspace, workspace_bytes,
+                         stream=None):
+        """unet_verify_split_dev: a few long records, one wavefront per 4 KiB segment."""
+        ic = iface.c()
+        _check(self.lib.unet_verify_split_dev(self.h, stream, d_arena, arena_bytes, d_off16, stride16, d_len, n, max_len, C.byref(ic), d_out,
+                                              d_workspace, workspace_bytes))
 
     def verify_bytes_dev(self, d_buf, buf_bytes, stride_bytes, length, n, iface: Iface, d_out, stream=None):
         """unet_verify_bytes_dev: n records of `length` bytes at a byte stride (no 16-byte slots, no tables)."""

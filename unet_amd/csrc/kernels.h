@@ -953,6 +953,68 @@ __global__ __launch_bounds__(kBlock, (TILE == 64 ? UNET_OCC64 : 6) * (256 / UNET
     if (t.lane < t.cnt) out[t.first + t.lane] = res;
 }
 
+// ------------------------------------------- a few long records: one wave per 4 KiB segment
+// One wave per record leaves a batch of a few jumbo frames (the loopback device carries up to 65535 bytes,
+// src/devices/loopback.rs:16) on a few waves, each pulling its record through row by row.  Here every segment of
+// kSegChunks chunks gets a wave of its own: wave (i, s) sums chunks [s * kSegChunks, (s + 1) * kSegChunks) of record i
+// -- exact u32 sums, segments start on 16-byte boundaries, so the segments' sums simply add up -- and leaves the
+// result in partial[i * max_segs + s]; k_verify_presummed then judges record i from its header bytes and that total.
+constexpr u32 kSegChunks = 256;  // 4 KiB
+
+__global__ __launch_bounds__(kBlock) void k_segment_sums(Batch b, u32 max_segs, u32* __restrict__ partial) {
+    const u32 lane = threadIdx.x & 63u;
+    const u32 w = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    const u32 i = w / max_segs, sg = w - i * max_segs;
+    if (i >= b.n) return;
+    const u32 len = b.len[i];
+    const u64 slot = b.off16 ? (u64)b.off16[i] : (u64)i * b.stride16;
+    const bool ok = len <= kMaxLen && slot <= 0xffffffffull && slot * 16u + (((u64)len + 15u) & ~15ull) <= b.arena_bytes;
+    const u32 nch = ok ? (len + 15u) >> 4 : 0u;
+    const u32 lo = sg * kSegChunks;
+    u32 acc = 0;
+    if (lo < nch) {
+        const u32 hi = min(nch, lo + kSegChunks);  // chunks [lo, hi) are this wave's
+        const u32x4* p = reinterpret_cast<const u32x4*>(b.arena) + slot;
+        const TailMask tm(len, nch);
+        // the four rows of a segment, requested together (clamped to the segment's last chunk, then left out)
+        const u32 last = hi - 1u;
+        const u32 c0 = lo + lane, c1 = c0 + kWave, c2 = c1 + kWave, c3 = c2 + kWave;
+        const u32x4 v0 = ld_stream(p + min(c0, last)), v1 = ld_stream(p + min(c1, last));
+        const u32x4 v2 = ld_stream(p + min(c2, last)), v3 = ld_stream(p + min(c3, last));
+        acc = sum_chunk(tm.apply(zero_unless(v0, c0 < hi), c0), acc);
+        acc = sum_chunk(tm.apply(zero_unless(v1, c1 < hi), c1), acc);
+        acc = sum_chunk(tm.apply(zero_unless(v2, c2 < hi), c2), acc);
+        acc = sum_chunk(tm.apply(zero_unless(v3, c3 < hi), c3), acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0u) partial[w] = acc;
+}
+
+// Dword k of a record in the arena (per-lane loads: only the few header dwords a verdict needs are touched).
+struct GlobalFetch {
+    const u32* w;
+    __device__ __forceinline__ u32 operator()(u32 k) const { return w[k]; }
+};
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_verify_presummed(Batch b, IfaceDev ifc, const u32* __restrict__ partial, u32 max_segs,
+                                                             u32* __restrict__ out) {
+    const u32 i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= b.n) return;
+    const u32 len = b.len[i];
+    const u64 slot = b.off16 ? (u64)b.off16[i] : (u64)i * b.stride16;
+    const bool ok = len <= kMaxLen && slot <= 0xffffffffull && slot * 16u + (((u64)len + 15u) & ~15ull) <= b.arena_bytes;
+    u32 res = 0;  // V_NONE, as the tile kernels answer for a record outside the arena -- and for one longer than the segments cover
+    if (ok && ((len + 15u) >> 4) <= max_segs * kSegChunks) {
+        u32 total = 0;
+        for (u32 s = 0; s < max_segs; ++s) total += partial[i * max_segs + s];
+        const GlobalFetch f{reinterpret_cast<const u32*>(b.arena + slot * 16u)};
+        const Parsed P = parse_record<MODE>(f, f, len, ifc);
+        res = P.kind == K_DONE ? P.res : finalize_record(P, total);
+    }
+    out[i] = res;
+}
+
 // ------------------------------------------- the same verdicts for records of ONE length at a BYTE stride
 // Records of `len` bytes, record i at byte i * stride of the buffer (stride >= len, both at most kBytesMaxLen): no
 // 16-byte slots, no tables.  A record of 65 bytes costs 80 bytes of arena and 8 bytes of tables in the slot layout

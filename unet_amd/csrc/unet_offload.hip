@@ -826,6 +826,62 @@ int unet_verify_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_
     return launch_verify(pick(ctx, stream), b, iface, pick_tile(ctx, arena_bytes, stride16, n), (u32*)d_out, ctx->lds_pad);
 }
 
+namespace {
+// Segments a record of max_len bytes is cut into by the split form (at least one).
+inline u32 split_segments(u32 max_len) { return max_len == 0 ? 1u : (((max_len + 15u) >> 4) + kSegChunks - 1u) / kSegChunks; }
+
+// A few long records: is the batch better judged one wave per 4 KiB segment than one wave per record?  Yes when the
+// usual tiling would leave most of the 256 CUs without a wave and the records are long enough to be worth cutting.
+inline bool want_split(u32 n, u64 mean_len, u32 max_len, int records_per_wave) {
+    const u64 waves = ((u64)n + (u32)records_per_wave - 1u) / (u32)records_per_wave;
+    return max_len >= 4u * kSegChunks * 16u && mean_len >= 2u * kSegChunks * 16u && waves < 128u && (u64)n * split_segments(max_len) <= 65536u;
+}
+
+int launch_split(hipStream_t s, const Batch& b, const unet_iface* iface, u32 max_len, u32* d_partial, u32* d_out) {
+    const u32 segs = split_segments(max_len), n = b.n;
+    const u64 waves = (u64)n * segs;
+    if (waves >= (1ull << 26)) return fail(UNET_E_RANGE, "%u records of up to %u bytes make %llu segments: too many for one launch", n, max_len, (unsigned long long)waves);
+    hipLaunchKernelGGL(k_segment_sums, dim3((u32)((waves + (kBlock / kWave) - 1) / (kBlock / kWave))), dim3(kBlock), 0, s, b, segs, d_partial);
+    HIP_TRY(hipGetLastError());
+    const IfaceDev ifc = to_dev(iface);
+    const dim3 grid((n + kBlock - 1) / kBlock);
+    if (iface->mode == UNET_MODE_L2)
+        hipLaunchKernelGGL(k_verify_presummed<MODE_L2>, grid, dim3(kBlock), 0, s, b, ifc, (const u32*)d_partial, segs, d_out);
+    else
+        hipLaunchKernelGGL(k_verify_presummed<MODE_L3>, grid, dim3(kBlock), 0, s, b, ifc, (const u32*)d_partial, segs, d_out);
+    HIP_TRY(hipGetLastError());
+    return UNET_OK;
+}
+}  // namespace
+
+int unet_verify_split_workspace(uint32_t n, uint32_t max_len, uint64_t* bytes) {
+    if (!bytes) return fail(UNET_E_INVAL, "null argument");
+    if (max_len > kMaxLen) return fail(UNET_E_RANGE, "max_len %u > 65535", max_len);
+    *bytes = (uint64_t)(n ? n : 1u) * split_segments(max_len) * 4u;
+    return UNET_OK;
+}
+
+int unet_verify_split_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint64_t arena_bytes, const uint32_t* d_off16,
+                          uint32_t stride16, const uint32_t* d_len, uint32_t n, uint32_t max_len, const unet_iface* iface,
+                          unet_result* d_out, void* d_workspace, uint64_t workspace_bytes) {
+    int rc = check_batch(ctx, d_arena, d_off16, stride16, d_len, n);
+    if (rc) return rc;
+    if (n == 0) return UNET_OK;
+    if (!iface || !d_out || !d_workspace) return fail(UNET_E_INVAL, "null argument");
+    if (arena_too_small(arena_bytes)) return fail(UNET_E_INVAL, "arena must hold at least 16 bytes");
+    if (iface->mode != UNET_MODE_L3 && iface->mode != UNET_MODE_L2) return fail(UNET_E_INVAL, "bad iface mode %d", iface->mode);
+    if (max_len > kMaxLen) return fail(UNET_E_RANGE, "max_len %u > 65535", max_len);
+    if (((uintptr_t)d_workspace & 3u) != 0) return fail(UNET_E_INVAL, "workspace must be 4-byte aligned");
+    uint64_t need = 0;
+    if ((rc = unet_verify_split_workspace(n, max_len, &need))) return rc;
+    if (workspace_bytes < need)
+        return fail(UNET_E_RANGE, "workspace of %llu bytes, %u records of up to %u bytes need %llu (unet_verify_split_workspace)",
+                    (unsigned long long)workspace_bytes, n, max_len, (unsigned long long)need);
+    HIP_TRY(hipSetDevice(ctx->device));
+    Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
+    return launch_split(pick(ctx, stream), b, iface, max_len, (u32*)d_workspace, (u32*)d_out);
+}
+
 int unet_verify_bytes_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t buf_bytes, uint32_t stride_bytes,
                           uint32_t len, uint32_t n, const unet_iface* iface, unet_result* d_out) {
     if (!ctx) return fail(UNET_E_INVAL, "null context");
@@ -873,6 +929,30 @@ int unet_verify(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const u
         fill_image(c, (uint8_t*)c->pinned[0], im, arena, off16, len, n);
         const int tile0 = c->tile_override ? c->tile_override : tile_for(im.sum_len / n, true, im.max_len);
         const int tile_here = in_place_tile(tile0);
+        if (!c->tile_override && want_split(n, im.sum_len / n, im.max_len, tile0)) {
+            // a few jumbo records: one wave per 4 KiB segment instead of a few waves working through whole records
+            const u64 part_bytes = (u64)n * split_segments(im.max_len) * 4u;  // at most 256 KiB (want_split)
+            if (im.total <= c->zero_copy_bytes) {
+                // read where the pinned image lies, like any small batch: now by hundreds of waves at once; results
+                // and the segments' sums go to the other pinned buffer
+                const u64 part_at = ((u64)n * 4u + 255u) & ~255ull;
+                if ((rc = launch_split(c->s_comp, image_batch((const uint8_t*)c->pinned_dev[0], im, off16 != nullptr, stride16, n), iface, im.max_len,
+                                       (u32*)((uint8_t*)c->pinned_dev[1] + part_at), (u32*)c->pinned_dev[1])))
+                    return rc;
+            } else {
+                const u64 part_at = (res_at + (u64)n * 4u + 255u) & ~255ull;
+                if ((rc = ensure(c, c->d_arena, part_at + part_bytes))) return rc;
+                uint8_t* dev = (uint8_t*)c->d_arena.p;
+                HIP_TRY(hipMemcpyAsync(dev, c->pinned[0], im.total, hipMemcpyHostToDevice, c->s_comp));
+                u32* d_out = (u32*)(dev + res_at);
+                if ((rc = launch_split(c->s_comp, image_batch(dev, im, off16 != nullptr, stride16, n), iface, im.max_len, (u32*)(dev + part_at), d_out))) return rc;
+                HIP_TRY(hipMemcpyAsync(c->pinned[1], d_out, (size_t)n * 4u, hipMemcpyDeviceToHost, c->s_comp));
+            }
+            HIP_TRY(hipStreamSynchronize(c->s_comp));
+            memcpy(out, c->pinned[1], (size_t)n * 4u);
+            count_on_host(c, (const u32*)c->pinned[1], n);
+            return UNET_OK;
+        }
         if (read_in_place(c, im.total, n, tile_here)) {
             // the kernel reads the image straight out of the pinned host buffer and writes the results into the
             // other one (both are mapped into the device's address space): one launch, one wait, no copy command
