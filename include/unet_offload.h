@@ -482,6 +482,12 @@ int unet_stream_read_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint
  * A benchmark takes the better of the two as what a pure read of its buffer attains on that GPU. */
 int unet_stream_read_pieces_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t bytes,
                                 uint32_t* d_sink);
+/* Debug builds only (hipcc -DUNET_DEBUG, e.g. tools/variants.sh debug): every store the kernels make into a
+ * wavefront's LDS area is checked against that area's bounds; a store outside is dropped and counted, and this call
+ * waits for the device and returns the count (reset != 0: and zeroes it).  A release build returns UNET_E_INVAL.
+ * No counterpart in the reference; it exists so that one run of the parity soak can rule out a whole class of
+ * wave-against-wave LDS races. */
+int unet_debug_lds_violations(unet_ctx* ctx, uint32_t* out, int reset);
 /* ------------------------------------------------ arena packing (host code, no GPU involved) */
 /* Bytes an arena needs for n records of these lengths, each padded to a 16-byte boundary (at least 16). */
 int unet_pack_size(const uint32_t* len, uint32_t n, uint64_t* arena_bytes);

@@ -14,3 +14,8 @@ def test_fuzz_rounds(offload):
         tx_round(offload, seed)
         dev_round(offload, seed)
         tx_dev_round(offload, seed)
+    # Against a -DUNET_DEBUG build of the library (UNET_OFFLOAD_LIB=.../variants/debug.so, tools/variants.sh debug) every
+    # LDS store of these rounds was bounds-checked: none may have fallen outside its wave's area.  A release build
+    # has no such counter.
+    bad = offload.debug_lds_violations()
+    assert bad in (None, 0), f"{bad} LDS stores outside their wave's area"

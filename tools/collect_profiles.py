@@ -28,7 +28,7 @@ def put(src, dst):
 
 
 kern = {"udp1500": "k_verify", "imix": "k_verify", "odd": "k_verify", "hdr20": "k_ipv4_validate_rows", "csum": "k_csum", "generate": "k_generate",
-        "txbuild": "k_tx_build"}
+        "txbuild": "k_tx_build", "tximix": "k_tx_build"}
 t = {}
 try:
     t = json.load(open("profiles/traffic.json"))
@@ -62,7 +62,11 @@ for w, k in kern.items():
           round(ro["achieved"]), "frac", round(ro["frac"], 3), "value", round(j["value"], 3), "traffic/alg", round(r["traffic_bytes"] / alg, 4),
           "parity", j.get("parity_check"))
 json.dump(t, open("profiles/traffic.json", "w"), indent=1)
-for src, dst in (("bench_fields.json", "bench_fields_1gpu.json"), ("bench_tximix.json", "bench_tximix_1gpu.json"),
+put(f"{P}/tcptrack_stats/s_kernel_stats.csv", f"{D}/tcptrack_kernel_stats.csv")
+for src, dst in (("bench_fields.json", "bench_fields_1gpu.json"), ("bench_txbuild_packed.json", "bench_txbuild_packed_layout_1gpu.json"),
+                 ("bench_udp1500_nccl_world1.json", "bench_udp1500_nccl_world1.json"), ("bench_tcptrack.json", "bench_tcptrack_1gpu.json"),
+                 ("size_sweep_l2.jsonl", "size_sweep_verify_csum_l2.jsonl"), ("tx_sweep_lines_fill.jsonl", "size_sweep_tx_build_lines_fill.jsonl"),
+                 ("split_latency.jsonl", "split_latency_few_long_records.jsonl"),
                  ("bench_eth1514.json", "bench_eth1514_l2_1gpu.json"), ("bench_udp1500_with_cpu.json", "bench_udp1500_with_cpu_baseline.json"),
                  ("bench_udp1500_emulated_rank3of8.json", "bench_udp1500_emulated_rank3of8.json"),
                  ("bench_trace_emulated_rank2of8_4chunks.json", "bench_trace_emulated_rank2of8_4chunks.json"),

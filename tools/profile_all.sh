@@ -12,7 +12,7 @@ OUT=$R/gpurun_out/profile_$tag
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 if [ "$part" = pmc ] || [ "$part" = all ]; then
-for w in udp1500 imix odd hdr20 csum generate txbuild; do
+for w in udp1500 imix odd hdr20 csum generate txbuild tximix; do
   extra=""
   [ "$w" = hdr20 ] || extra="--rotate 1"
   timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${w}_stats" -o s -- python3 "$R/bench.py" --workload "$w" --cpu-seconds 0 > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err" || exit 1
@@ -23,10 +23,14 @@ done
 fi
 if [ "$part" = bench ] || [ "$part" = all ]; then
 cd "$R"
-for w in fields tximix eth1514; do
+for w in fields eth1514; do
   timeout -k 10 200 python3 bench.py --workload $w --cpu-seconds 0 > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err" || exit 2
   echo "bench $w"
 done
+timeout -k 10 200 python3 bench.py --workload txbuild --tx-layout packed --cpu-seconds 0 > "$OUT/bench_txbuild_packed.json" 2>> "$OUT/bench.err" || exit 2
+timeout -k 10 200 python3 bench.py --force-dist --cpu-seconds 0 > "$OUT/bench_udp1500_nccl_world1.json" 2>> "$OUT/bench.err" || exit 2
+( cd /tmp && timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/tcptrack_stats" -o s -- python3 "$R/bench.py" --workload tcptrack --steps 10 --cpu-seconds 0 > "$OUT/bench_tcptrack.json" 2> "$OUT/bench_tcptrack.err" ) || exit 2
+echo "bench tcptrack"
 timeout -k 10 300 python3 bench.py --workload udp1500 --cpu-seconds 10 > "$OUT/bench_udp1500_with_cpu.json" 2> "$OUT/bench_udp1500_with_cpu.err" || exit 2
 timeout -k 10 300 python3 bench.py --workload udp1500 --emulate-world 8 --emulate-rank 3 --cpu-seconds 0 > "$OUT/bench_udp1500_emulated_rank3of8.json" 2>> "$OUT/bench.err" || exit 2
 timeout -k 10 300 python3 bench.py --workload trace --emulate-world 8 --emulate-rank 2 --steps 4 --cpu-seconds 0 > "$OUT/bench_trace_emulated_rank2of8_4chunks.json" 2>> "$OUT/bench.err" || exit 2
@@ -36,10 +40,13 @@ timeout -k 10 300 python3 tools/host_path_bench.py > "$OUT/host_path_pcie_inclus
 fi
 if [ "$part" = sweeps ] || [ "$part" = all ]; then
 cd "$R"
-timeout -k 10 500 python3 tools/size_sweep.py 20 40 64 65 80 81 96 100 112 113 128 160 208 256 400 512 576 577 800 1024 1040 1499 1500 2048 4096 9000 65535 > "$OUT/size_sweep.jsonl" 2> "$OUT/size_sweep.err" || exit 3
-echo "size sweep done"
+UNET_SWEEP_BYTES=1 timeout -k 10 500 python3 tools/size_sweep.py 20 28 40 46 60 64 65 74 80 81 96 100 112 113 128 160 208 256 400 512 576 577 800 1024 1040 1499 1500 2048 4096 9000 65535 > "$OUT/size_sweep.jsonl" 2> "$OUT/size_sweep.err" || exit 3
+UNET_SWEEP_L2=1 UNET_SWEEP_BYTES=1 timeout -k 10 300 python3 tools/size_sweep.py 60 64 74 100 128 590 1514 > "$OUT/size_sweep_l2.jsonl" 2>> "$OUT/size_sweep.err" || exit 3
+echo "size sweeps done"
 timeout -k 10 500 python3 tools/tx_sweep.py > "$OUT/tx_sweep.jsonl" 2> "$OUT/tx_sweep.err" || exit 3
-echo "tx sweep done"
+TX_SWEEP_LINE_ALIGNED=1 timeout -k 10 500 python3 tools/tx_sweep.py 1000 1472 2000 3000 4000 6000 8972 20000 65507 > "$OUT/tx_sweep_lines_fill.jsonl" 2>> "$OUT/tx_sweep.err" || exit 3
+echo "tx sweeps done"
+timeout -k 10 300 python3 tools/split_latency.py both > "$OUT/split_latency.jsonl" 2> "$OUT/split_latency.err" || exit 3
 timeout -k 10 500 python3 tools/batch_sweep.py > "$OUT/batch_sweep.jsonl" 2> "$OUT/batch_sweep.err" || exit 3
 echo "batch sweep done"
 fi

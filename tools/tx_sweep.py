@@ -36,9 +36,11 @@ for mode in (0, 1):
         d_olen = torch.zeros(n, dtype=torch.int32, device="cuda")
         d_st = torch.zeros(n, dtype=torch.uint8, device="cuda")
 
+        flags = 1 if os.environ.get("TX_SWEEP_LINE_ALIGNED") else 0  # UNET_TX_FILL_LINES: the slots are the caller's up to the line's end
+
         def run():
             ctx.tx_build_dev(buf.data_ptr(), n * slots * 16, None, slots, d_plen.data_ptr(), d_desc.data_ptr(), n, ifc, d_out.data_ptr(),
-                             n * oslots * 16, d_ooff.data_ptr(), d_olen.data_ptr(), d_st.data_ptr(), st.cuda_stream)
+                             n * oslots * 16, d_ooff.data_ptr(), d_olen.data_ptr(), d_st.data_ptr(), st.cuda_stream, flags=flags)
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -49,6 +51,6 @@ for mode in (0, 1):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
         assert int(d_st.max().item()) == 0 and int(d_olen.min().item()) == flen
-        print(json.dumps({"mode": "L2" if mode else "L3", "payload": L, "packet": flen, "packets": n,
+        print(json.dumps({"mode": "L2" if mode else "L3", "layout": "lines+fill" if flags else "packed", "payload": L, "packet": flen, "packets": n,
                           "GBps": round(n * (L + flen + 41) / ms / 1e6, 1), "Gpkt_s": round(n / ms / 1e6, 3)}), flush=True)
         del d_out

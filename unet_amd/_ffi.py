@@ -201,6 +201,7 @@ _SIGS = {
     "unet_stream_read_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p]),
     "unet_stream_read_pieces_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p]),
     "unet_stream_copy_dev": (C.c_int, [_vp, _vp, _u8p, _u8p, C.c_uint64]),
+    "unet_debug_lds_violations": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.c_int]),
 }
 
 EXPORTS = tuple(_SIGS)
@@ -624,6 +625,13 @@ class Offload:
 
     def stream_read_pieces_dev(self, d_buf, nbytes, d_sink, stream=None):
         _check(self.lib.unet_stream_read_pieces_dev(self.h, stream, d_buf, nbytes, d_sink))
+
+    def debug_lds_violations(self, reset: bool = False):
+        """Out-of-area LDS stores counted by a -DUNET_DEBUG build, or None when the library is a release build."""
+        v = C.c_uint32(0)
+        if self.lib.unet_debug_lds_violations(self.h, C.byref(v), 1 if reset else 0) != 0:
+            return None
+        return int(v.value)
 
     def stream_copy_dev(self, d_src, d_dst, nbytes, stream=None):
         _check(self.lib.unet_stream_copy_dev(self.h, stream, d_src, d_dst, nbytes))

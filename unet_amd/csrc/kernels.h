@@ -27,6 +27,22 @@ struct Batch {
     u32 tile_n = 0;  // records per wave if fewer than the kernel's TILE (0: TILE)
 };
 
+// Every store into a wave's LDS area goes through this: in a -DUNET_DEBUG build a store whose chunk index lies outside the
+// area it is meant for is counted (unet_debug_lds_violations) and dropped instead of landing in a neighbouring
+// wave's area, where it would show up as one wrong header byte in a few thousand batches.  Release builds store
+// unconditionally: the index arithmetic is the same, the check costs registers the short-record kernels do not have.
+#ifdef UNET_DEBUG
+__device__ unsigned int g_lds_out_of_area = 0;
+#define UNET_LDS_STORE(BASE, IDX, LIMIT, V)                        \
+    do {                                                           \
+        const u32 i_ = (IDX);                                      \
+        if (i_ < (u32)(LIMIT)) (BASE)[i_] = (V);                   \
+        else atomicAdd(&g_lds_out_of_area, 1u);                    \
+    } while (0)
+#else
+#define UNET_LDS_STORE(BASE, IDX, LIMIT, V) ((void)(LIMIT), (BASE)[(IDX)] = (V))
+#endif
+
 // Build-time switches for A/B measurements (each path can be compiled out; the wave-cooperative path then
 // takes those records).
 #ifndef UNET_MID_PATH
@@ -244,10 +260,10 @@ __device__ __forceinline__ u32 stream_one(const Rows2& cur, u32 lane, u32x4* __r
     const bool partial = (cur.flen & 15u) != 0u;  // chunk `nfull` exists and is cut short
     const bool two = cur.two();
     const u32 i1 = lane + cur.tail_base();        // chunk held by this lane's `tail`
-    u32x4* mine = park + (cur.j % PASS) * kLdsChunksPerRec;
-    if (PARK_HDR && lane < kHdrChunks) mine[lane] = pick_chunk(two, cur.head, cur.tail);
+    const u32 at = (cur.j % PASS) * kLdsChunksPerRec;  // the record's slot of the park area (PASS slots)
+    if (PARK_HDR && lane < kHdrChunks) UNET_LDS_STORE(park, at + lane, PASS * kLdsChunksPerRec, pick_chunk(two, cur.head, cur.tail));
     // the cut chunk is the record's last one: always in `tail`
-    if (partial && i1 == nfull) mine[kHdrChunks] = cur.tail;
+    if (partial && i1 == nfull) UNET_LDS_STORE(park, at + kHdrChunks, PASS * kLdsChunksPerRec, cur.tail);
     const u32x4 a = zero_unless(cur.head, two);
     const u32x4 c = zero_unless(cur.tail, i1 < nfull);
     u32 acc = sum_chunk(a, 0u);
@@ -378,14 +394,15 @@ template <u32 W, bool PARK_HDR, u32 PASS>
 __device__ __forceinline__ void consume_rows_step(const RowStep& g, u32 lane, u32x4* __restrict__ park, u32* __restrict__ sums) {
     const u32 sub = lane & (W - 1u);
     const u32 nfull = g.row_live ? g.len >> 4 : 0u;
-    u32x4* mine = park + (g.rec % PASS) * kLdsChunksPerRec;
+    const u32 at = (g.rec % PASS) * kLdsChunksPerRec;
+    constexpr u32 kLimit = PASS * kLdsChunksPerRec;
     if (PARK_HDR && g.row_live) {  // chunks 0..5: in v0 for W >= 8, in v0 and v1 for W = 4
-        if (sub < kHdrChunks) mine[sub] = g.v0;
-        if (W < kHdrChunks && sub + W < kHdrChunks) mine[sub + W] = g.v1;
+        if (sub < kHdrChunks) UNET_LDS_STORE(park, at + sub, kLimit, g.v0);
+        if (W < kHdrChunks && sub + W < kHdrChunks) UNET_LDS_STORE(park, at + sub + W, kLimit, g.v1);
     }
     if (g.row_live && (g.len & 15u) != 0u && sub == (nfull & (W - 1u))) {
         const u32 w = nfull / W;  // which of the four loads holds the cut chunk
-        mine[kHdrChunks] = w == 0u ? g.v0 : (w == 1u ? g.v1 : (w == 2u ? g.v2 : g.v3));
+        UNET_LDS_STORE(park, at + kHdrChunks, kLimit, w == 0u ? g.v0 : (w == 1u ? g.v1 : (w == 2u ? g.v2 : g.v3)));
     }
     u32 acc = sum_chunk(zero_unless(g.v0, sub < nfull), 0u);
     acc = sum_chunk(zero_unless(g.v1, sub + W < nfull), acc);
@@ -474,11 +491,18 @@ __device__ __forceinline__ u32 span_sums(const SpanPlan& sp, Tile& t, u32x4* __r
     // With 16-record tiles the wave's LDS area is 112 chunks, less than two rows: there only the chunks of the range
     // are stored.  (The 256 chunks of the larger tiles hold four whole rows; testing there as well costs them 16
     // registers and two waves per SIMD.)
+    // (UNET_DEBUG_SPAN_WHOLE_ROWS brings back the fault this condition repairs -- whole rows stored into the small area of
+    // 16-record tiles -- as a self-test of the -DUNET_DEBUG build: its counter must then move)
+#ifdef UNET_DEBUG_SPAN_WHOLE_ROWS
+    constexpr bool kWholeRows = true;
+#else
     constexpr bool kWholeRows = TileGeom<TILE>::kPark >= 4u * kWave;
-    if (sp.rows > 0u && (kWholeRows || t.lane < sp.span)) park[t.lane] = sp.r0;
-    if (sp.rows > 1u && (kWholeRows || kWave + t.lane < sp.span)) park[kWave + t.lane] = sp.r1;
-    if (sp.rows > 2u && (kWholeRows || 2u * kWave + t.lane < sp.span)) park[2u * kWave + t.lane] = sp.r2;
-    if (sp.rows > 3u && (kWholeRows || 3u * kWave + t.lane < sp.span)) park[3u * kWave + t.lane] = sp.r3;
+#endif
+    constexpr u32 kLimit = TileGeom<TILE>::kPark;
+    if (sp.rows > 0u && (kWholeRows || t.lane < sp.span)) UNET_LDS_STORE(park, t.lane, kLimit, sp.r0);
+    if (sp.rows > 1u && (kWholeRows || kWave + t.lane < sp.span)) UNET_LDS_STORE(park, kWave + t.lane, kLimit, sp.r1);
+    if (sp.rows > 2u && (kWholeRows || 2u * kWave + t.lane < sp.span)) UNET_LDS_STORE(park, 2u * kWave + t.lane, kLimit, sp.r2);
+    if (sp.rows > 3u && (kWholeRows || 3u * kWave + t.lane < sp.span)) UNET_LDS_STORE(park, 3u * kWave + t.lane, kLimit, sp.r3);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const u32 my_nch = (t.my_len + 15u) >> 4;
@@ -570,13 +594,14 @@ __device__ __forceinline__ void stream_row(const u32x4 v, const u32x4 w, u32 row
     const u32 c0 = carry + (u32)(S & 1ull) - 1u;
     const u32 rid = __builtin_amdgcn_mbcnt_hi((u32)(S1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)S1, c0));
     carry += (u32)__builtin_popcountll(S);
-    u32x4* area = park + rid * kLdsChunksPerRec;
+    const u32 at = rid * kLdsChunksPerRec;  // record rid's slot: one per record of the tile, the bitmaps lie behind them
+    constexpr u32 kLimit = (u32)TILE * kLdsChunksPerRec;
     // wave-uniform masks become per-lane conditions with no vector arithmetic
     if (PARK_HDR) {
         const u32 ci = row * kWave + t.lane - from_lane(my_rel, rid);
-        if (__builtin_amdgcn_inverse_ballot_w64(valid) && ci < kHdrChunks) area[ci] = v;
+        if (__builtin_amdgcn_inverse_ballot_w64(valid) && ci < kHdrChunks) UNET_LDS_STORE(park, at + ci, kLimit, v);
     }
-    if (__builtin_amdgcn_inverse_ballot_w64(C & valid)) area[kHdrChunks] = v;
+    if (__builtin_amdgcn_inverse_ballot_w64(C & valid)) UNET_LDS_STORE(park, at + kHdrChunks, kLimit, v);
     const u32 P = wave_prefix(sum_chunk(zero_unless(v, __builtin_amdgcn_inverse_ballot_w64(valid & ~C)), 0u));
     // the last lane of every run: the lane before a record start, and the row's last chunk
     const u64 before_start = S1 & valid;
@@ -741,7 +766,7 @@ __device__ __forceinline__ u32 tile_sums(const Batch& b, Tile& t, u32 pass, u32x
 #define UNET_SMALL_LOAD(i) const u32x4 s##i = ld_small(p + min((u32)(i), last))
 #define UNET_SMALL_USE(i)                                                           \
         {                                                                           \
-            if (PARK_HDR && (i) < kHdrChunks) mine[i] = s##i;                       \
+            if (PARK_HDR && (i) < kHdrChunks) UNET_LDS_STORE(park, (t.lane % PASS) * kLdsChunksPerRec + (i), PASS * kLdsChunksPerRec, s##i); \
             const bool in = (u32)(i) <= last, cut = (u32)(i) == last;               \
             u32x4 v = zero_unless(s##i, in);                                        \
             v.x &= cut ? k0 : 0xffffffffu;                                          \
@@ -848,15 +873,17 @@ __device__ __forceinline__ u32 lane_loop_pass(const Batch& b, Tile& t, u32 pass,
     for (u32 c = 0; c < nch; c += 4u) {
         const u32x4 v0 = ld_small(p + min(c, last)), v1 = ld_small(p + min(c + 1u, last));
         const u32x4 v2 = ld_small(p + min(c + 2u, last)), v3 = ld_small(p + min(c + 3u, last));
+        const u32 at = (t.lane % PASS) * kLdsChunksPerRec;
+        constexpr u32 kLimit = PASS * kLdsChunksPerRec;
         if (PARK_HDR && c == 0u) {
-            mine[0] = v0;
-            mine[1] = v1;
-            mine[2] = v2;
-            mine[3] = v3;
+            UNET_LDS_STORE(park, at, kLimit, v0);
+            UNET_LDS_STORE(park, at + 1u, kLimit, v1);
+            UNET_LDS_STORE(park, at + 2u, kLimit, v2);
+            UNET_LDS_STORE(park, at + 3u, kLimit, v3);
         }
         if (PARK_HDR && c == 4u) {
-            mine[4] = v0;
-            mine[5] = v1;
+            UNET_LDS_STORE(park, at + 4u, kLimit, v0);
+            UNET_LDS_STORE(park, at + 5u, kLimit, v1);
         }
 #define UNET_LOOP_USE(V, I)                                                         \
         {                                                                           \
@@ -1071,7 +1098,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_verify_bytes(const uint8_t* __res
     }
 #pragma unroll
     for (u32 k = 0; k < kBytesRows; ++k)
-        if (k * kWave + lane < span) area[k * kWave + lane] = r[k];
+        if (k * kWave + lane < span) UNET_LDS_STORE(area, k * kWave + lane, kBytesArea, r[k]);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const u32 nfull = len >> 4;
@@ -1687,8 +1714,9 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx
         for (int q = 0; q < 4; ++q) h[n++] = bswap16(l4[q]);
 #pragma unroll
         for (u32 c = 0; c < SH; ++c) {
-            park[t.lane * SH + c] = u32x4{h[8 * c] | (h[8 * c + 1] << 16), h[8 * c + 2] | (h[8 * c + 3] << 16),
-                                          h[8 * c + 4] | (h[8 * c + 5] << 16), h[8 * c + 6] | (h[8 * c + 7] << 16)};
+            UNET_LDS_STORE(park, t.lane * SH + c, TILE * SH,
+                           (u32x4{h[8 * c] | (h[8 * c + 1] << 16), h[8 * c + 2] | (h[8 * c + 3] << 16), h[8 * c + 4] | (h[8 * c + 5] << 16),
+                                  h[8 * c + 6] | (h[8 * c + 7] << 16)}));
         }
     }
     if (t.lane < t.cnt) {

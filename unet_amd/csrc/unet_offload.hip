@@ -1747,6 +1747,26 @@ int unet_stream_read_pieces_dev(unet_ctx* ctx, void* stream, const uint8_t* d_bu
     return UNET_OK;
 }
 
+int unet_debug_lds_violations(unet_ctx* ctx, uint32_t* out, int reset) {
+    if (!ctx || !out) return fail(UNET_E_INVAL, "null argument");
+#ifdef UNET_DEBUG
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned int v = 0;
+    HIP_TRY(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_lds_out_of_area), sizeof v));
+    *out = v;
+    if (reset) {
+        v = 0;
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_lds_out_of_area), &v, sizeof v));
+    }
+    return UNET_OK;
+#else
+    (void)reset;
+    *out = 0;
+    return fail(UNET_E_INVAL, "this library was not built with -DUNET_DEBUG: its kernels do not check their LDS stores");
+#endif
+}
+
 /* ---------------------------------------------------------------- arena packing */
 int unet_pack_size(const uint32_t* len, uint32_t n, uint64_t* arena_bytes) {
     if ((n && !len) || !arena_bytes) return fail(UNET_E_INVAL, "null argument");
