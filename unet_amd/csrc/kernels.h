@@ -1660,7 +1660,10 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx
     }
     const bool any = todo != 0ull;
     const u64 mid_mask = __ballot(my_mid);
-    if (any && mid_mask == 0ull) {  // the first payloads are on their way while the headers are prepared
+#ifndef UNET_TX_EARLY_BIG
+#define UNET_TX_EARLY_BIG 0   // k_tx_build: the first whole-wave payloads are requested ahead of the lane-group and single-lane packets too
+#endif
+    if (any && (UNET_TX_EARLY_BIG || mid_mask == 0ull)) {  // the first payloads are on their way while the headers are prepared
 #pragma unroll
         for (int k = 0; k < D - 1; ++k) UNET_NEXT(buf[k])
     }
@@ -1732,7 +1735,7 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx
         if (UNET_TX_G4) tx_rows_path<4, R, SH>(pay, t, my_g4, store_len, my_oslot, my_partial, my_udp, list, out_arena, park);
         tx_rows_path<8, R, SH>(pay, t, my_g8, store_len, my_oslot, my_partial, my_udp, list, out_arena, park);
         tx_rows_path<16, R, SH>(pay, t, my_mid && !my_g4 && !my_g8, store_len, my_oslot, my_partial, my_udp, list, out_arena, park);
-        if (any) {
+        if (any && !UNET_TX_EARLY_BIG) {
 #pragma unroll
             for (int k = 0; k < D - 1; ++k) UNET_NEXT(buf[k])
         }
