@@ -132,6 +132,38 @@ def test_oracle_tx_build_status_codes():
 
 # ------------------------------------------------------------------------------------------ GPU
 
+TX_KERNEL_KNOBS = {
+    "by_mean_payload": {},
+    "tile_kernel": {"UNET_TX_WAVE": "0"},
+    "one_packet_per_wave": {"UNET_TX_WAVE": "2", "UNET_TXW_GROUP": "1"},
+    "two_waves_per_packet": {"UNET_TX_WAVE": "2", "UNET_TXW_GROUP": "2"},
+    "four_waves_per_packet": {"UNET_TX_WAVE": "2", "UNET_TXW_GROUP": "4"},
+    "sixteen_waves_per_packet": {"UNET_TX_WAVE": "2", "UNET_TXW_GROUP": "16"},
+}
+
+
+@pytest.fixture(scope="module", params=list(TX_KERNEL_KNOBS))
+def offload(request):
+    """Every GPU test of this file once per way of building a batch: the library's own choice between its two transmit
+    kernels (by mean payload length), the tile kernel for every batch, and one packet per wave or per group of 2, 4 or
+    16 waves for every batch (the knobs are read when the context is opened)."""
+    import os
+    knobs = TX_KERNEL_KNOBS[request.param]
+    old = {k: os.environ.get(k) for k in ("UNET_TX_WAVE", "UNET_TXW_GROUP")}
+    for k in old:
+        os.environ.pop(k, None)
+    os.environ.update(knobs)
+    try:
+        ctx = unet_amd.Offload(0)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    yield ctx
+    ctx.close()
+
+
 def _gpu_build(offload, arena, off16, plen, desc, ifc, ooff, obytes, fill=0xAB, stride16=0, flags=0):
     import torch
     assert torch.cuda.is_available()

@@ -1,0 +1,139 @@
+// Does a packet builder's copy depend on how full its 1 KiB row instructions are, and on where its rows start?
+// One record of P chunks per wave (or two records per wave with their short second rows sharing one instruction),
+// input at a stride of IS chunks, output at OS chunks; every wave copies and ends.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/row_shape_probe.hip -o tools/row_shape_probe.bin
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+// one record per wave: rows of 64 chunks, the last one as full as it is
+__global__ __launch_bounds__(256) void k_single(const u32x4* __restrict__ src, u32x4* __restrict__ dst, u32 n, u32 P, u32 IS, u32 OS,
+                                                u32 in_lead) {
+    const u32 lane = threadIdx.x & 63u;
+    const u32 w = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (w >= n) return;
+    const u32x4* p = src + in_lead + (u64)w * IS;
+    u32x4* q = dst + (u64)w * OS;
+    const u32 last = P - 1u;
+    const u32x4 a = __builtin_nontemporal_load(p + min(lane, last));
+    const u32x4 b = __builtin_nontemporal_load(p + min(lane + 64u, last));
+    if (lane < P) __builtin_nontemporal_store(a, q + lane);
+    if (lane + 64u < P) __builtin_nontemporal_store(b, q + lane + 64u);
+}
+
+// two records of P = 64 + T chunks (T <= 32) per wave: three instructions each way, the middle one carrying both
+// records' second rows (lanes 0..31 record A, lanes 32..63 record B)
+__global__ __launch_bounds__(256) void k_pair(const u32x4* __restrict__ src, u32x4* __restrict__ dst, u32 n, u32 P, u32 IS, u32 OS,
+                                              u32 in_lead) {
+    const u32 lane = threadIdx.x & 63u;
+    const u32 w = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (2u * w + 1u >= n) return;
+    const u32x4* pa = src + in_lead + (u64)(2u * w) * IS;
+    const u32x4* pb = pa + IS;
+    u32x4* qa = dst + (u64)(2u * w) * OS;
+    u32x4* qb = qa + OS;
+    const u32 T = P - 64u, half = lane & 31u;
+    const bool second = lane >= 32u;
+    const u32x4 a = __builtin_nontemporal_load(pa + lane);
+    const u32x4 m = __builtin_nontemporal_load((second ? pb : pa) + 64u + min(half, T - 1u));
+    const u32x4 b = __builtin_nontemporal_load(pb + lane);
+    __builtin_nontemporal_store(a, qa + lane);
+    if (half < T) __builtin_nontemporal_store(m, (second ? qb : qa) + 64u + half);
+    __builtin_nontemporal_store(b, qb + lane);
+}
+
+// R records per wave, one after another, the next record's two rows requested before the current one is stored
+__global__ __launch_bounds__(256) void k_single_loop(const u32x4* __restrict__ src, u32x4* __restrict__ dst, u32 n, u32 P, u32 IS, u32 OS,
+                                                     u32 in_lead, u32 R) {
+    const u32 lane = threadIdx.x & 63u;
+    const u32 w = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const u32 first = w * R;
+    if (first >= n) return;
+    const u32 cnt = min(R, n - first), last = P - 1u;
+    const u32x4* p = src + in_lead + (u64)first * IS;
+    u32x4* q = dst + (u64)first * OS;
+    u32x4 a = __builtin_nontemporal_load(p + min(lane, last));
+    u32x4 b = __builtin_nontemporal_load(p + min(lane + 64u, last));
+    for (u32 r = 0; r < cnt; ++r) {
+        const u32x4* pn = p + (r + 1u < cnt ? IS : 0u);
+        const u32x4 na = __builtin_nontemporal_load(pn + min(lane, last));
+        const u32x4 nb = __builtin_nontemporal_load(pn + min(lane + 64u, last));
+        if (lane < P) __builtin_nontemporal_store(a, q + lane);
+        if (lane + 64u < P) __builtin_nontemporal_store(b, q + lane + 64u);
+        a = na;
+        b = nb;
+        p = pn;
+        q += OS;
+    }
+}
+
+template <typename F>
+double timeit(F f, int iters) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    f();
+    f();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < iters; i++) f();
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return ms / iters;
+}
+
+__global__ void k_fill_random(u64* buf, u64 nwords) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (u64)gridDim.x * blockDim.x) {
+        u64 z = i * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        buf[i] = z ^ (z >> 31);
+    }
+}
+
+int main() {
+    const u64 bytes = 3ull << 30;
+    uint8_t *s, *d;
+    CK(hipMalloc(&s, bytes + 4096));
+    CK(hipMalloc(&d, bytes + 4096));
+    hipLaunchKernelGGL(k_fill_random, dim3(65536), dim3(256), 0, 0, (u64*)s, bytes / 8);
+    CK(hipMemset(d, 0, bytes));
+    CK(hipDeviceSynchronize());
+    const u64 nchunks = bytes / 16;
+    struct Case { u32 P, IS, OS, lead; };
+    // P chunks copied per record; lead: the input starts that many chunks off a 128-byte line
+    const Case cases[] = {{64, 64, 64, 0},   {96, 96, 96, 0},   {128, 128, 128, 0}, {96, 96, 128, 0},  {96, 128, 128, 0},
+                          {94, 94, 94, 0},   {94, 92, 96, 0},   {96, 92, 96, 0},    {96, 92, 96, 2},   {72, 72, 72, 0},
+                          {80, 80, 80, 0},   {112, 112, 112, 0}, {65, 65, 72, 0},   {72, 65, 72, 0}};
+    for (const Case& c : cases) {
+        const u32 stride = c.IS > c.OS ? c.IS : c.OS;
+        const u32 n = (u32)((nchunks - 64) / stride) & ~1u;
+        const double moved = 2.0 * n * c.P * 16.0;
+        for (int block : {256, 64}) {
+            const int wpb = block / 64;
+            double ms = timeit([&] { hipLaunchKernelGGL(k_single, dim3((n + wpb - 1) / wpb), dim3(block), 0, 0, (const u32x4*)s, (u32x4*)d, n, c.P, c.IS, c.OS, c.lead); }, 6);
+            printf("P %3u in-stride %3u out-stride %3u lead %u block %3d  single %7.1f GB/s", c.P, c.IS, c.OS, c.lead, block, moved / ms / 1e6);
+            if (c.P > 64 && c.P <= 96) {
+                ms = timeit([&] { hipLaunchKernelGGL(k_pair, dim3((n / 2 + wpb - 1) / wpb), dim3(block), 0, 0, (const u32x4*)s, (u32x4*)d, n, c.P, c.IS, c.OS, c.lead); }, 6);
+                printf("  pair %7.1f", moved / ms / 1e6);
+            } else printf("  pair       -");
+            for (u32 R : {4u, 8u}) {
+                const u32 waves = (n + R - 1) / R;
+                ms = timeit([&] { hipLaunchKernelGGL(k_single_loop, dim3((waves + wpb - 1) / wpb), dim3(block), 0, 0, (const u32x4*)s, (u32x4*)d, n, c.P, c.IS, c.OS, c.lead, R); }, 6);
+                printf("  loop%u %7.1f", R, moved / ms / 1e6);
+            }
+            printf("\n");
+            fflush(stdout);
+        }
+    }
+    return 0;
+}

@@ -75,9 +75,6 @@ __device__ unsigned int g_lds_out_of_area = 0;
 #ifndef UNET_TX_MID_PATH
 #define UNET_TX_MID_PATH 1    // k_tx_build: lane groups for packets of up to 64 chunks
 #endif
-#ifndef UNET_TX_BURST
-#define UNET_TX_BURST 1       // k_tx_build: rows 2.. of a long payload requested four at a time (0: one at a time, in rotation)
-#endif
 #ifndef UNET_TX_G4
 #define UNET_TX_G4 1          // k_tx_build: groups of 4 lanes for packets of up to 16 chunks
 #endif
@@ -1311,105 +1308,94 @@ __device__ __forceinline__ TxRows issue_rows_shifted(const Batch& b, u32 my_len,
     return x;
 }
 
-// Builds one packet from the payload in `cur` and its prepared headers.  The packet is treated as one
-// byte stream, headers then payload, cut into the payload's 16-byte chunks: "virtual" chunk m holds stream
-// bytes [16m - R, 16m - R + 16), so chunks 0..SH-1 are the headers (parked in LDS by their lane, L4
-// checksum still blank) and chunk SH + k is payload chunk k.  Output chunk m = bytes R..15 of virtual
-// chunk m followed by bytes 0..R-1 of virtual chunk m + 1, which sits in the next lane's registers.
-// Returns nothing: rows 0/1 are stored last, whole, once the payload's sum has completed the L4 checksum
-// (the last 16-bit word of virtual chunk SH-1 for UDP, the third-last for ICMP).  The part of a payload
-// past rows 0/1 is streamed through before that.
+// Where tx_build_one's lanes 0..SH-1 take their header chunk from: parked in LDS by the packet's lane (tile kernel),
+// or in every lane's registers (one packet per wave).
+struct TxHdrLds {
+    const u32x4* p;
+    __device__ __forceinline__ u32x4 operator()(u32 lane) const { return p[lane]; }
+};
+template <u32 SH>
+struct TxHdrRegs {
+    u32x4 c[SH];
+    __device__ __forceinline__ u32x4 operator()(u32 lane) const {
+        u32x4 v = c[0];
+#pragma unroll
+        for (u32 k = 1; k < SH; ++k) v = pick_chunk(lane == k, c[k], v);
+        return v;
+    }
+};
+
+// One packet as the row code sees it: payload chunks in, output chunks out.
+struct TxPkt {
+    const u32x4* p;   // payload
+    u32x4* pout;      // packet
+    u32 nin, nout;    // payload chunks, output chunks the stores may cover
+    u32 last;         // index of the last payload chunk (0 for an empty payload)
+    TailMask tm;
+    __device__ __forceinline__ TxPkt(const u32x4* p_, u32 payload_len, u32 nin_, u32 store_len, u32x4* pout_)
+        : p(p_), pout(pout_), nin(nin_), nout((store_len + 15u) >> 4), last(nin_ != 0u ? nin_ - 1u : 0u), tm(payload_len, nin_) {}
+    // payload chunk k as it enters the packet: zero past the payload's end, the cut last chunk masked
+    __device__ __forceinline__ u32x4 chunk(u32 k) const { return tm.apply(zero_unless(ld_stream(p + min(k, last)), k < nin), k); }
+};
+
+// Payload chunks [k, k_end) of a packet, k on a row boundary of the output (k + SH a multiple of 64): rows of 64 chunks,
+// four rows requested together with the first chunk of the row after them (one address for the whole wave), then each
+// row spliced with the first dwords of the next and stored; the last step asks only for the rows that exist.  The loads
+// are clamped to the payload's last chunk and zeroed past its end.  more_behind: the packet goes on past k_end (in
+// another wave's hands).  Returns acc + the lanes' sums over these chunks.
 template <int R, u32 SH>
-__device__ __forceinline__ void tx_build_one(const TxRows& cur, u32 lane, u32 frame_len, u32x4* __restrict__ pout,
-                                             const u32x4* __restrict__ hdr, u32 l4_partial_be, bool udp) {
-    const u32 nin = cur.nch, nout = (frame_len + 15u) >> 4;
-    const TailMask tm(cur.flen, nin);
-    const u32 k0 = lane - SH, k1 = lane + kWave - SH;  // k0 wraps for the header lanes: they hold no payload
-    u32x4 a = tm.apply(zero_unless(cur.r0, lane >= SH && k0 < nin), k0);
-    const u32x4 c = tm.apply(zero_unless(cur.r1, k1 < nin), k1);
-    u32 acc = sum_chunk(c, sum_chunk(a, 0u));
-    // Payloads past rows 0/1: further rows of 64 chunks, four register buffers in rotation so that three
-    // rows are on their way while one is spliced (with the first dwords of the row after it) and stored.
-    // The loads are unconditional and clamped to the last chunk, then zeroed past the payload's end.
-    constexpr u32 kRows = 2u * kWave - SH;
-    const u32 kend = max(nin, nout - SH);
-    const u32 last = nin != 0u ? nin - 1u : 0u;
-    u32 fx = 0, fy = 0;  // first dwords of the chunk after row 1, wanted by lane 63 of row 1
-    if (kRows < kend) {
-        u32 k = kRows;
-#define UNET_TX_ROW(X, K) const u32 idx_##X = (K) + lane; X = tm.apply(zero_unless(ld_stream(cur.p + min(idx_##X, last)), idx_##X < nin), idx_##X)
+__device__ __forceinline__ u32 tx_rows(const TxPkt& t, u32 lane, u32 k, u32 k_end, u32 acc, bool more_behind) {
+#define UNET_TX_ROW(X, K) X = t.chunk((K) + lane)
 #define UNET_TX_EMIT(X, NEXT, K)                                                                  \
-        {                                                                                         \
-            acc = sum_chunk(X, acc);                                                              \
-            u32x4 h_ = {0, 0, 0, 0};                                                              \
-            h_.x = from_next_lane(X.x, rdlane(NEXT.x, 0));                                        \
-            if (R > 4) h_.y = from_next_lane(X.y, rdlane(NEXT.y, 0));                             \
-            if ((K) + lane + SH < nout) tx_store(splice<R>(X, h_), pout + (K) + lane + SH);       \
-        }
-        u32x4 ra, rb, rc, rd;
-#if UNET_TX_BURST
-        // four rows requested together with the first chunk of the row after them (one address for the whole wave),
-        // then spliced and stored
-        {
-            const u32x4 pk = tm.apply(zero_unless(ld_stream(cur.p + min(k, last)), k < nin), k);
-            fx = rdlane(pk.x, 0);
-            fy = rdlane(pk.y, 0);
-        }
+    {                                                                                             \
+        acc = sum_chunk(X, acc);                                                                  \
+        u32x4 h_ = {0, 0, 0, 0};                                                                  \
+        h_.x = from_next_lane(X.x, rdlane(NEXT.x, 0));                                            \
+        if (R > 4) h_.y = from_next_lane(X.y, rdlane(NEXT.y, 0));                                 \
+        if ((K) + lane + SH < t.nout) tx_store(splice<R>(X, h_), t.pout + (K) + lane + SH);       \
+    }
+    u32x4 ra, rb, rc, rd;
 #pragma nounroll
-        for (; k + 4u * kWave <= kend; k += 4u * kWave) {
-            const u32 kn = k + 4u * kWave;
-            { UNET_TX_ROW(ra, k); }
-            { UNET_TX_ROW(rb, k + kWave); }
-            { UNET_TX_ROW(rc, k + 2u * kWave); }
-            { UNET_TX_ROW(rd, k + 3u * kWave); }
-            const u32x4 pk = tm.apply(zero_unless(ld_stream(cur.p + min(kn, last)), kn < nin), kn);
-            UNET_TX_EMIT(ra, rb, k)
-            UNET_TX_EMIT(rb, rc, k + kWave)
-            UNET_TX_EMIT(rc, rd, k + 2u * kWave)
-            UNET_TX_EMIT(rd, pk, k + 3u * kWave)
-        }
-        if (k < kend) {  // fewer than 256 chunks are left: only the rows that hold some of them are requested
-            const bool has_b = k + kWave < kend, has_c = k + 2u * kWave < kend, has_d = k + 3u * kWave < kend;
-            const u32x4 zero = {0, 0, 0, 0};
-            rb = rc = rd = zero;
-            { UNET_TX_ROW(ra, k); }
-            if (has_b) { UNET_TX_ROW(rb, k + kWave); }
-            if (has_c) { UNET_TX_ROW(rc, k + 2u * kWave); }
-            if (has_d) { UNET_TX_ROW(rd, k + 3u * kWave); }
-            UNET_TX_EMIT(ra, rb, k)
-            if (has_b) UNET_TX_EMIT(rb, rc, k + kWave)
-            if (has_c) UNET_TX_EMIT(rc, rd, k + 2u * kWave)
-            if (has_d) UNET_TX_EMIT(rd, zero, k + 3u * kWave)
-        }
-#else
-        { UNET_TX_ROW(ra, k); }
-        { UNET_TX_ROW(rb, k + kWave); }
-        { UNET_TX_ROW(rc, k + 2u * kWave); }
-        fx = rdlane(ra.x, 0);
-        fy = rdlane(ra.y, 0);
-#pragma nounroll
-        while (true) {
-            { UNET_TX_ROW(rd, k + 3u * kWave); }
-            UNET_TX_EMIT(ra, rb, k)
-            if (k + kWave >= kend) break;
-            { UNET_TX_ROW(ra, k + 4u * kWave); }
-            UNET_TX_EMIT(rb, rc, k + kWave)
-            if (k + 2u * kWave >= kend) break;
-            { UNET_TX_ROW(rb, k + 5u * kWave); }
-            UNET_TX_EMIT(rc, rd, k + 2u * kWave)
-            if (k + 3u * kWave >= kend) break;
-            { UNET_TX_ROW(rc, k + 6u * kWave); }
-            UNET_TX_EMIT(rd, ra, k + 3u * kWave)
-            k += 4u * kWave;
-            if (k >= kend) break;
-        }
-#endif
+    for (; k + 4u * kWave <= k_end; k += 4u * kWave) {
+        UNET_TX_ROW(ra, k);
+        UNET_TX_ROW(rb, k + kWave);
+        UNET_TX_ROW(rc, k + 2u * kWave);
+        UNET_TX_ROW(rd, k + 3u * kWave);
+        const u32x4 pk = t.chunk(k + 4u * kWave);
+        UNET_TX_EMIT(ra, rb, k)
+        UNET_TX_EMIT(rb, rc, k + kWave)
+        UNET_TX_EMIT(rc, rd, k + 2u * kWave)
+        UNET_TX_EMIT(rd, pk, k + 3u * kWave)
+    }
+    if (k < k_end) {  // fewer than 256 chunks are left: only the rows that hold some of them are requested
+        const bool has_b = k + kWave < k_end, has_c = k + 2u * kWave < k_end, has_d = k + 3u * kWave < k_end;
+        // the chunk behind the last of these rows: zero when the packet ends here, another wave's when only the range does
+        u32x4 pk = {0, 0, 0, 0};
+        if (more_behind) pk = t.chunk(k + (has_d ? 4u : (has_c ? 3u : (has_b ? 2u : 1u))) * kWave);
+        rb = rc = rd = pk;
+        UNET_TX_ROW(ra, k);
+        if (has_b) { UNET_TX_ROW(rb, k + kWave); }
+        if (has_c) { UNET_TX_ROW(rc, k + 2u * kWave); }
+        if (has_d) { UNET_TX_ROW(rd, k + 3u * kWave); }
+        UNET_TX_EMIT(ra, rb, k)
+        if (has_b) UNET_TX_EMIT(rb, rc, k + kWave)
+        if (has_c) UNET_TX_EMIT(rc, rd, k + 2u * kWave)
+        if (has_d) UNET_TX_EMIT(rd, pk, k + 3u * kWave)
+    }
 #undef UNET_TX_ROW
 #undef UNET_TX_EMIT
-    }
-    const u32 pay_be = bswap16(fold16(wave_sum(acc)));  // payload's folded sum, big-endian domain
+    return acc;
+}
+
+// Rows 0/1 of a packet, stored whole once the payload's exact sum `total` has completed the L4 checksum (the last
+// 16-bit word of virtual chunk SH-1 for UDP, the third-last for ICMP).  a, c: the masked payload chunks of rows 0/1 as
+// loaded by issue_rows_shifted; fx, fy: first dwords of the payload chunk behind row 1.
+template <int R, u32 SH, class Hdr>
+__device__ __forceinline__ void tx_finish(const TxPkt& t, u32 lane, u32x4 a, u32x4 c, u32 fx, u32 fy, u32 total, const Hdr& hdr,
+                                          u32 l4_partial_be, bool udp) {
+    const u32 pay_be = bswap16(fold16(total));  // payload's folded sum, big-endian domain
     const u32 ck = bswap16((~fold16(l4_partial_be + pay_be)) & 0xffffu) << 16;
-    if (lane < SH) a = hdr[lane];
+    if (lane < SH) a = hdr(lane);
     if (lane == SH - 1u) {
         a.w |= udp ? ck : 0u;
         a.z |= udp ? 0u : ck;
@@ -1421,8 +1407,36 @@ __device__ __forceinline__ void tx_build_one(const TxRows& cur, u32 lane, u32 fr
         ha.y = from_next_lane(a.y, rdlane(c.y, 0));
         hc.y = from_next_lane(c.y, fy);
     }
-    if (lane < nout) tx_store(splice<R>(a, ha), pout + lane);
-    if (lane + kWave < nout) tx_store(splice<R>(c, hc), pout + lane + kWave);
+    if (lane < t.nout) tx_store(splice<R>(a, ha), t.pout + lane);
+    if (lane + kWave < t.nout) tx_store(splice<R>(c, hc), t.pout + lane + kWave);
+}
+
+constexpr u32 tx_rows01_chunks(u32 SH) { return 2u * kWave - SH; }  // payload chunks that rows 0/1 of a packet hold
+
+// Builds one packet from the payload in `cur` and its prepared headers.  The packet is treated as one
+// byte stream, headers then payload, cut into the payload's 16-byte chunks: "virtual" chunk m holds stream
+// bytes [16m - R, 16m - R + 16), so chunks 0..SH-1 are the headers (L4 checksum still blank) and chunk SH + k is
+// payload chunk k.  Output chunk m = bytes R..15 of virtual chunk m followed by bytes 0..R-1 of virtual
+// chunk m + 1, which sits in the next lane's registers.  The part of a payload past rows 0/1 is streamed
+// through first (tx_rows); rows 0/1 are stored last (tx_finish).
+template <int R, u32 SH, class Hdr>
+__device__ __forceinline__ void tx_build_one(const TxRows& cur, u32 lane, u32 frame_len, u32x4* __restrict__ pout,
+                                             const Hdr& hdr, u32 l4_partial_be, bool udp) {
+    const TxPkt t(cur.p, cur.flen, cur.nch, frame_len, pout);
+    const u32 k0 = lane - SH, k1 = lane + kWave - SH;  // k0 wraps for the header lanes: they hold no payload
+    const u32x4 a = t.tm.apply(zero_unless(cur.r0, lane >= SH && k0 < t.nin), k0);
+    const u32x4 c = t.tm.apply(zero_unless(cur.r1, k1 < t.nin), k1);
+    u32 acc = sum_chunk(c, sum_chunk(a, 0u));
+    constexpr u32 kRows = tx_rows01_chunks(SH);
+    const u32 kend = max(t.nin, t.nout - SH);
+    u32 fx = 0, fy = 0;  // first dwords of the chunk after row 1, wanted by lane 63 of row 1
+    if (kRows < kend) {
+        const u32x4 pk = t.chunk(kRows);
+        fx = rdlane(pk.x, 0);
+        fy = rdlane(pk.y, 0);
+        acc = tx_rows<R, SH>(t, lane, kRows, kend, acc, false);
+    }
+    tx_finish<R, SH>(t, lane, a, c, fx, fy, wave_sum(acc), hdr, l4_partial_be, udp);
 }
 
 // A packet with a payload of at most 3 chunks (48 bytes: measured break-even with the 4-lane groups), built
@@ -1592,6 +1606,63 @@ __device__ __forceinline__ void tx_rows_path(const Batch& pay, const Tile& t, bo
     __builtin_amdgcn_wave_barrier();
 }
 
+// The headers of one packet as its first SH virtual chunks (see tx_build_one): little-endian halves of the wire
+// bytes, R bytes to the right, the L4 checksum field still zero.  Returns the L4 checksum's partial sum (pseudo-header
+// and L4 header for UDP, the ICMP header otherwise) in the big-endian domain.
+template <int MODE>
+__device__ __forceinline__ u32 tx_headers(const TxDesc& d, u32 payload_len, u32 proto, const IfaceDev& ifc,
+                                          u32x4 (&chunk)[MODE == MODE_L2 ? 3 : 2]) {
+    constexpr u32 SH = MODE == MODE_L2 ? 3u : 2u;
+    constexpr int R = MODE == MODE_L2 ? 6 : 4;
+    const u32 src = ifc.unicast, dst = d.dst;
+    // create_ip_header, src/protocols/ipv4.rs:366-391
+    const u32 ip[10] = {0x4500u, (20u + (8u + payload_len)) & 0xffffu, d.id_proto & 0xffffu, 0u, (64u << 8) | proto, 0u,
+                        src >> 16, src & 0xffffu, dst >> 16, dst & 0xffffu};
+    u32 ipsum = 0;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) ipsum += ip[q];
+    const u32 ipck = (~fold16(ipsum)) & 0xffffu;
+    u32 l4[4], partial;
+    if (proto == 17u) {
+        // udp::send, src/transport/udp.rs:181-203: the pseudo-header uses the caller's src address
+        const u32 length = (8u + payload_len) & 0xffffu;
+        l4[0] = d.l4ab & 0xffffu;
+        l4[1] = d.l4ab >> 16;
+        l4[2] = length;
+        l4[3] = 0u;
+        partial = (d.src >> 16) + (d.src & 0xffffu) + (dst >> 16) + (dst & 0xffffu) + 17u + length + l4[0] + l4[1] + l4[2];
+    } else {
+        // icmp::send, src/transport/icmp.rs:75-85
+        l4[0] = d.l4ab & 0xffffu;  // type << 8 | code
+        l4[1] = 0u;
+        l4[2] = d.values >> 16;
+        l4[3] = d.values & 0xffffu;
+        partial = l4[0] + l4[2] + l4[3];
+    }
+    u32 h[8 * SH];
+    int n = 0;
+#pragma unroll
+    for (int q = 0; q < R / 2; ++q) h[n++] = 0u;
+    if (MODE == MODE_L2) {
+        h[n++] = d.mac_lo & 0xffffu;
+        h[n++] = d.mac_lo >> 16;
+        h[n++] = d.mac_hi & 0xffffu;
+        h[n++] = ifc.mac_lo & 0xffffu;
+        h[n++] = ifc.mac_lo >> 16;
+        h[n++] = ifc.mac_hi & 0xffffu;
+        h[n++] = 0x0008u;  // 08 00
+    }
+#pragma unroll
+    for (int q = 0; q < 10; ++q) h[n++] = bswap16(q == 5 ? ipck : ip[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) h[n++] = bswap16(l4[q]);
+#pragma unroll
+    for (u32 c = 0; c < SH; ++c)
+        chunk[c] = u32x4{h[8 * c] | (h[8 * c + 1] << 16), h[8 * c + 2] | (h[8 * c + 3] << 16), h[8 * c + 4] | (h[8 * c + 5] << 16),
+                         h[8 * c + 6] | (h[8 * c + 7] << 16)};
+    return partial;
+}
+
 // MODE_L3: packet = 28 header bytes + payload.  MODE_L2: 42 header bytes + payload (+ tap::send's pad).
 // Lane j first prepares packet j's headers (every field and the IPv4 checksum; the L4 checksum as a
 // partial sum) and parks them in LDS; the wave then builds the packets one after another, reading each
@@ -1668,59 +1739,14 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx
         for (int k = 0; k < D - 1; ++k) UNET_NEXT(buf[k])
     }
 
-    // ---- headers as big-endian 16-bit words, checksums in that domain
+    // ---- headers (tx_headers), parked as virtual chunks 0..SH-1
     u32 my_partial = 0;
     const bool my_udp = proto == 17u;
     if (my_go) {
-        const u32 src = ifc.unicast, dst = d.dst;
-        // create_ip_header, src/protocols/ipv4.rs:366-391
-        const u32 ip[10] = {0x4500u, (20u + (8u + t.my_len)) & 0xffffu, d.id_proto & 0xffffu, 0u, (64u << 8) | proto, 0u,
-                            src >> 16, src & 0xffffu, dst >> 16, dst & 0xffffu};
-        u32 ipsum = 0;
+        u32x4 hc[SH];
+        my_partial = tx_headers<MODE>(d, t.my_len, proto, ifc, hc);
 #pragma unroll
-        for (int q = 0; q < 10; ++q) ipsum += ip[q];
-        const u32 ipck = (~fold16(ipsum)) & 0xffffu;
-        u32 l4[4];
-        if (my_udp) {
-            // udp::send, src/transport/udp.rs:181-203: the pseudo-header uses the caller's src address
-            const u32 length = (8u + t.my_len) & 0xffffu;
-            l4[0] = d.l4ab & 0xffffu;
-            l4[1] = d.l4ab >> 16;
-            l4[2] = length;
-            l4[3] = 0u;
-            my_partial = (d.src >> 16) + (d.src & 0xffffu) + (dst >> 16) + (dst & 0xffffu) + 17u + length + l4[0] + l4[1] + l4[2];
-        } else {
-            // icmp::send, src/transport/icmp.rs:75-85
-            l4[0] = d.l4ab & 0xffffu;  // type << 8 | code
-            l4[1] = 0u;
-            l4[2] = d.values >> 16;
-            l4[3] = d.values & 0xffffu;
-            my_partial = l4[0] + l4[2] + l4[3];
-        }
-        // little-endian halves of the wire bytes, R bytes to the right (the virtual chunks of tx_build_one)
-        u32 h[8 * SH];
-        int n = 0;
-#pragma unroll
-        for (int q = 0; q < R / 2; ++q) h[n++] = 0u;
-        if (MODE == MODE_L2) {
-            h[n++] = d.mac_lo & 0xffffu;
-            h[n++] = d.mac_lo >> 16;
-            h[n++] = d.mac_hi & 0xffffu;
-            h[n++] = ifc.mac_lo & 0xffffu;
-            h[n++] = ifc.mac_lo >> 16;
-            h[n++] = ifc.mac_hi & 0xffffu;
-            h[n++] = 0x0008u;  // 08 00
-        }
-#pragma unroll
-        for (int q = 0; q < 10; ++q) h[n++] = bswap16(q == 5 ? ipck : ip[q]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) h[n++] = bswap16(l4[q]);
-#pragma unroll
-        for (u32 c = 0; c < SH; ++c) {
-            UNET_LDS_STORE(park, t.lane * SH + c, TILE * SH,
-                           (u32x4{h[8 * c] | (h[8 * c + 1] << 16), h[8 * c + 2] | (h[8 * c + 3] << 16), h[8 * c + 4] | (h[8 * c + 5] << 16),
-                                  h[8 * c + 6] | (h[8 * c + 7] << 16)}));
-        }
+        for (u32 c = 0; c < SH; ++c) UNET_LDS_STORE(park, t.lane * SH + c, TILE * SH, hc[c]);
     }
     if (t.lane < t.cnt) {
         out_len[i] = st == UNET_TX_OK_ ? frame_len : 0u;
@@ -1750,7 +1776,7 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx
     // in flight while one packet is assembled and stored
 #define UNET_CONSUME(X)                                                              \
     tx_build_one<R, SH>(X, t.lane, rdlane(store_len, X.j),                           \
-                        reinterpret_cast<u32x4*>(out_arena + (u64)rdlane(my_oslot, X.j) * 16u), park + X.j * SH, \
+                        reinterpret_cast<u32x4*>(out_arena + (u64)rdlane(my_oslot, X.j) * 16u), TxHdrLds{park + X.j * SH}, \
                         rdlane(my_partial, X.j), rdlane((u32)my_udp, X.j) != 0u);
     if (any) {
         bool more = true;
@@ -1768,6 +1794,119 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx
     }
 #undef UNET_NEXT
 #undef UNET_CONSUME
+}
+
+// One packet per wave -- or per group of 2, 4, 8 or 16 waves of one workgroup -- for batches of long payloads (mean
+// above 1 KiB).  A wave reads its packet's table entries and descriptor through the scalar unit; the packet's rows of
+// 64 output chunks are dealt out to the group's waves in consecutive runs (at least two rows each, about four at the
+// batch's mean length); every wave copies its run (tx_rows), the group's first wave also holds rows 0/1 back until
+// the payload's sum is known: each wave leaves the exact sum of its rows in LDS, one workgroup barrier, and the first
+// wave completes the L4 checksum and stores rows 0/1 (tx_finish).  Why not tiles: a device-to-device copy runs 10 %
+// faster in waves that move one 1.5 KiB record and end than in waves that loop over four or eight of them (6.0 against
+// 5.3 TB/s: short waves keep the chip's reads and writes inside one narrow moving window), and the tile kernel's
+// per-wave set-up (64 lanes of table loads, LDS parking, 100 registers) is what made one packet per wave slow there.
+// Correct for every payload length; short payloads waste their wave.
+constexpr u32 kTxGroupMax = 16;  // waves per packet at most (one workgroup of 1024 threads)
+
+// Packet i, built by wave w of a group of 1 << group_log2 waves (`wv`: this wave's number in its workgroup, `part`:
+// the workgroup's sums; neither is used by a group of one).  POLICY bit 0: row 0 of the payload non-temporal, bit 1:
+// row 1 (which holds the end of most payloads).  WRITE_META: out_len and status are stored too.
+template <int MODE, int POLICY, bool WRITE_META>
+__device__ __forceinline__ void tx_wave_packet(const Batch& pay, const TxDesc* __restrict__ desc, const IfaceDev& ifc,
+                                               uint8_t* __restrict__ out_arena, u64 out_bytes, const u32* __restrict__ out_off16,
+                                               u32* __restrict__ out_len, uint8_t* __restrict__ status, u32 flags, u32 i, bool have,
+                                               u32 w, u32 group_log2, u32 wv, u32* __restrict__ part, u32 lane) {
+    constexpr u32 SH = MODE == MODE_L2 ? 3u : 2u;
+    constexpr int R = MODE == MODE_L2 ? 6 : 4;
+    constexpr u32 kRows = tx_rows01_chunks(SH);
+    const u32 group = 1u << group_log2;
+    u32 len = 0, oslot = 0, st = UNET_TX_E_RANGE_, frame_len = 0, proto = 0;
+    u64 slot = 0;
+    TxDesc d = {};
+    if (have) {
+        len = pay.len[i];
+        slot = pay.off16 ? (u64)pay.off16[i] : (u64)i * pay.stride16;
+        oslot = out_off16[i];
+        d = desc[i];
+        proto = (d.id_proto >> 16) & 0xffu;
+        const u32 l3len = 28u + len;
+        frame_len = MODE == MODE_L2 ? 14u + max(l3len, 60u) : l3len;  // src/driver/tap.rs:147-152
+        // the same checks, in the same order, as the tile kernel
+        const bool in_ok = len <= kMaxLen && slot <= 0xffffffffull && slot * 16u + (((u64)len + 15u) & ~15ull) <= pay.arena_bytes;
+        st = UNET_TX_OK_;
+        if (!in_ok) st = UNET_TX_E_RANGE_;
+        else if (!(proto == 1u || proto == 17u)) st = UNET_TX_E_PROTO_;
+        else if (len > 65535u - 20u - 8u) st = UNET_TX_E_TOO_LONG_;  // src/transport/udp.rs:174-180
+        else if ((u64)oslot * 16u + (((u64)frame_len + 15u) & ~15ull) > out_bytes) st = UNET_TX_E_RANGE_;
+        if (WRITE_META && w == 0u && lane == 0u) {
+            out_len[i] = st == UNET_TX_OK_ ? frame_len : 0u;
+            if (status) status[i] = (uint8_t)st;
+        }
+    }
+    const bool go = have && st == UNET_TX_OK_;
+    u32 store_len = frame_len;  // (kTxFillLines: see k_tx_build)
+    if (go && (flags & kTxFillLines) != 0u) {
+        const u32 end = oslot + ((frame_len + 15u) >> 4);
+        const u32 upto = (end + 7u) & ~7u;
+        if (upto >= end && (u64)upto * 16u <= out_bytes) store_len = (upto - oslot) * 16u;
+    }
+    const u32 nin = go ? (len + 15u) >> 4 : 0u;
+    // an empty payload may sit at the very end of the arena: read the arena's first chunk instead
+    const TxPkt t(reinterpret_cast<const u32x4*>(pay.arena + (nin != 0u ? slot * 16u : 0ull)), len, nin, go ? store_len : 0u,
+                  reinterpret_cast<u32x4*>(out_arena + (u64)oslot * 16u));
+    const u32 kend = max(t.nin, t.nout - SH);                 // payload chunks (or zeros) the output covers
+    const u32 rows = go ? (kend + SH + kWave - 1u) / kWave : 0u;  // rows of 64 output chunks
+    const u32 per = max(2u, (rows + group - 1u) >> group_log2);  // rows per wave of the group
+    u32 acc = 0, fx = 0, fy = 0;
+    u32x4 a = {0, 0, 0, 0}, c = a;
+    if (w == 0u) {
+        if (go) {
+            const u32x4* p0 = t.p + min(lane < SH ? 0u : lane - SH, t.last);
+            const u32x4* p1 = t.p + min(lane + kWave - SH, t.last);
+            const u32x4 r0 = (POLICY & 1) ? __builtin_nontemporal_load(p0) : *p0;
+            const u32x4 r1 = (POLICY & 2) ? __builtin_nontemporal_load(p1) : *p1;
+            const u32 k0 = lane - SH, k1 = lane + kWave - SH;  // k0 wraps for the header lanes: they hold no payload
+            a = t.tm.apply(zero_unless(r0, lane >= SH && k0 < t.nin), k0);
+            c = t.tm.apply(zero_unless(r1, k1 < t.nin), k1);
+            acc = sum_chunk(c, sum_chunk(a, 0u));
+            if (kRows < kend) {
+                const u32x4 pk = t.chunk(kRows);
+                fx = rdlane(pk.x, 0);
+                fy = rdlane(pk.y, 0);
+                if (per > 2u) acc = tx_rows<R, SH>(t, lane, kRows, min(kend, per * kWave - SH), acc, per * kWave - SH < kend);
+            }
+        }
+    } else {
+        const u32 r_begin = w * per;
+        if (r_begin < rows) acc = tx_rows<R, SH>(t, lane, r_begin * kWave - SH, min(kend, (r_begin + per) * kWave - SH), acc, (r_begin + per) * kWave - SH < kend);
+    }
+    u32 total = wave_sum(acc);
+    if (group > 1u) {  // (wave-uniform, and the same for every wave of the launch)
+        if (lane == 0u) part[wv] = total;
+        __syncthreads();
+        if (w == 0u) {
+            total = 0u;
+            for (u32 k = 0; k < group; ++k) total += part[wv + k];  // exact: a payload's bytes sum to less than 2^31
+        }
+    }
+    if (w == 0u && go) {
+        TxHdrRegs<SH> hdr;
+        const u32 partial = tx_headers<MODE>(d, len, proto, ifc, hdr.c);
+        tx_finish<R, SH>(t, lane, a, c, fx, fy, total, hdr, partial, proto == 17u);
+    }
+}
+
+template <int MODE, int POLICY>
+__global__ __launch_bounds__(kTxGroupMax * kWave) void k_tx_build_wave(Batch pay, const TxDesc* __restrict__ desc, IfaceDev ifc,
+                                                                       uint8_t* __restrict__ out_arena, u64 out_bytes,
+                                                                       const u32* __restrict__ out_off16, u32* __restrict__ out_len,
+                                                                       uint8_t* __restrict__ status, u32 flags, u32 group_log2) {
+    __shared__ u32 part[kTxGroupMax];  // per wave of the workgroup: the sum of its rows
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const u32 gw = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + wv));
+    const u32 i = gw >> group_log2, w = gw & ((1u << group_log2) - 1u);  // packet, wave of its group
+    tx_wave_packet<MODE, POLICY, true>(pay, desc, ifc, out_arena, out_bytes, out_off16, out_len, status, flags, i, i < pay.n, w, group_log2,
+                                       wv, part, lane);
 }
 
 // ------------------------------------------------------------------ verdict histogram

@@ -198,6 +198,10 @@ struct unet_ctx {
     int tile_override = 0;        // UNET_TILE, read once at unet_open
     int tx_tile_override = 0;     // UNET_TX_TILE (1, 2, 4, 8, 16, 32, 64), read once at unet_open
     int tile_once = 0;            // records per wave for the launch a host-pointer entry point is about to make
+    int tx_wave = 1;              // UNET_TX_WAVE: 0 = every batch goes through the tile kernel, 2 = every batch one packet per wave (A/B, tests)
+    u32 tx_wave_block = 256;      // UNET_TXW_BLOCK: threads per workgroup of k_tx_build_wave (64, 128 or 256; more when a packet's group of waves needs it)
+    int tx_wave_policy = -1;      // UNET_TXW_POLICY (experiments): cache policy of the two row loads of k_tx_build_wave instead of the choice by mean payload
+    int tx_group_log2 = -1;       // UNET_TXW_GROUP (1, 2, 4, 8, 16): waves per packet of k_tx_build_wave instead of the choice by mean payload
     bool hdr_plain = false;       // UNET_HDR_PLAIN, read once at unet_open
     u32 lds_pad = 0;              // UNET_LDS_PAD: bytes of unused LDS added to every workgroup of the record kernels (experiments: fewer resident workgroups)
     u32 mean_len_hint = 0;        // unet_hint_mean_len
@@ -354,6 +358,12 @@ inline int tx_tile_for(u64 mean_payload) {
     if (mean_payload > 1024) return tx_tile_long(mean_payload);
     if (mean_payload >= 600) return 16;
     return mean_payload <= 112 ? 64 : 32;
+}
+
+// Waves per packet of k_tx_build_wave (as a power of two) by mean payload: about three rows of 64 output chunks per wave.
+inline u32 tx_group_log2_for(u64 mean_payload, bool l2) {
+    const u64 rows = (mean_payload + (l2 ? 42u : 28u) + 1023u) / 1024u;
+    return rows <= 3 ? 0u : (rows <= 6 ? 1u : (rows <= 12 ? 2u : (rows <= 24 ? 3u : 4u)));
 }
 
 inline hipStream_t pick(unet_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->s_comp; }
@@ -588,6 +598,16 @@ int unet_open(int device_id, unet_ctx** out_ctx) {
     c->hdr_plain = getenv("UNET_HDR_PLAIN") != nullptr;
     if (const char* t = getenv("UNET_LDS_PAD")) c->lds_pad = (u32)strtoul(t, nullptr, 10);
     if (const char* z = getenv("UNET_ZERO_COPY_BYTES")) c->zero_copy_bytes = strtoull(z, nullptr, 10);
+    if (const char* t = getenv("UNET_TX_WAVE")) c->tx_wave = atoi(t);
+    if (const char* t = getenv("UNET_TXW_BLOCK")) {
+        const int v = atoi(t);
+        c->tx_wave_block = v <= 64 ? 64u : (v <= 128 ? 128u : 256u);
+    }
+    if (const char* t = getenv("UNET_TXW_POLICY")) c->tx_wave_policy = atoi(t);
+    if (const char* t = getenv("UNET_TXW_GROUP")) {
+        const int v = atoi(t);
+        c->tx_group_log2 = v <= 1 ? 0 : (v <= 2 ? 1 : (v <= 4 ? 2 : (v <= 8 ? 3 : 4)));
+    }
     if (const char* t = getenv("UNET_TX_TILE")) {
         const int v = atoi(t);
         c->tx_tile_override = v <= 1 ? 1 : (v <= 2 ? 2 : (v <= 4 ? 4 : (v <= 8 ? 8 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)))));
@@ -1263,9 +1283,38 @@ int unet_tx_build_opts_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload
 #define UNET_TX_LAUNCH(M, T)                                                                                             \
     hipLaunchKernelGGL((k_tx_build<M, T>), dim3(tiles_grid(n, b.tile_n)), dim3(kBlock), ctx->lds_pad, pick(ctx, stream), b, (const TxDesc*)d_desc, ifc, \
                        d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status, flags)
-    int tile = tx_tile_for(pick_mean(ctx, payload_arena_bytes, payload_stride16, n));
+    const u64 mean_payload = pick_mean(ctx, payload_arena_bytes, payload_stride16, n);
+    int tile = tx_tile_for(mean_payload);
     if (ctx->tx_tile_override) tile = ctx->tx_tile_override;
     b.tile_n = (u32)tile;  // fewer packets per wave than the smallest instantiation: that kernel, part of its lanes
+    // Long payloads (mean above 1 KiB): one packet per wave or group of waves, see k_tx_build_wave.  (A launch holds
+    // fewer than 2^32 threads; a batch too large for that stays with the tile kernel.)
+    if (ctx->tx_wave == 2 || (ctx->tx_wave == 1 && !ctx->tx_tile_override && tile <= 8)) {
+        const u32 g2 = ctx->tx_group_log2 >= 0 ? (u32)ctx->tx_group_log2 : tx_group_log2_for(mean_payload, iface->mode == UNET_MODE_L2);
+        const u32 group = 1u << g2;
+        const u32 wpb = group > ctx->tx_wave_block / kWave ? group : ctx->tx_wave_block / kWave;  // waves per workgroup
+        const u64 blocks = ((u64)n * group + wpb - 1) / wpb;
+        if (blocks * wpb * kWave < (1ull << 32)) {
+            const dim3 grid((u32)blocks), block(wpb * kWave);
+#define UNET_TXW_LAUNCH(M, P)                                                                                                      \
+    hipLaunchKernelGGL((k_tx_build_wave<M, P>), grid, block, 0, pick(ctx, stream), b, (const TxDesc*)d_desc, ifc, d_out_arena, \
+                       out_arena_bytes, d_out_off16, d_out_len, d_status, flags, g2)
+            const bool l2 = iface->mode == UNET_MODE_L2;
+            // Both rows streaming while row 1 is at most half full (1472-byte payloads: 6.17 against 5.95 TB/s), row 1 --
+            // the row a payload of up to 2 KiB ends in -- cached beyond that (2000 B: 6.53 against 6.14); row 0 cached too
+            // is never better by more than 2 % and costs 7 % at 1100 B.
+            const int policy = ctx->tx_wave_policy >= 0 ? ctx->tx_wave_policy : (mean_payload <= 1600 ? 3 : 1);
+            switch (policy & 3) {
+            case 0: if (l2) UNET_TXW_LAUNCH(MODE_L2, 0); else UNET_TXW_LAUNCH(MODE_L3, 0); break;
+            case 1: if (l2) UNET_TXW_LAUNCH(MODE_L2, 1); else UNET_TXW_LAUNCH(MODE_L3, 1); break;
+            case 2: if (l2) UNET_TXW_LAUNCH(MODE_L2, 2); else UNET_TXW_LAUNCH(MODE_L3, 2); break;
+            default: if (l2) UNET_TXW_LAUNCH(MODE_L2, 3); else UNET_TXW_LAUNCH(MODE_L3, 3); break;
+            }
+#undef UNET_TXW_LAUNCH
+            HIP_TRY(hipGetLastError());
+            return UNET_OK;
+        }
+    }
     if ((rc = check_tiles(n, b.tile_n))) return rc;
     if (iface->mode == UNET_MODE_L2) {
         if (tile <= 8) UNET_TX_LAUNCH(MODE_L2, 8);
