@@ -517,7 +517,7 @@ def main():
     op = args.workload if args.workload in ("csum", "generate", "fields", "txbuild", "eth1514", "tximix", "tcptrack") else "verify"
     batches = [Batch(ctx, stream, kind, ifc, r * n_global, n_global, shard_world, shard_rank, stride16, op) for r in range(rotate)]
     b0 = batches[0]
-    kernel = {"tcptrack": "k_verify<MODE_L3> + k_tcp_keys + DeviceRadixSort + k_tcp_apply + k_tcp_apply_long", "csum": "k_csum", "generate": "k_generate", "fields": "k_generate<read only>", "txbuild": "k_tx_build<MODE_L3>", "tximix": "k_tx_build<MODE_L3>", "eth1514": "k_verify<MODE_L2>"}.get(op, "k_ipv4_validate_rows" if kind == unet_amd.SYNTH_IPV4_HDR20 else "k_verify<MODE_L3>")
+    kernel = {"tcptrack": "k_verify<MODE_L3> + k_tcp_keys + DeviceRadixSort + k_tcp_apply + k_tcp_apply_long", "csum": "k_csum", "generate": "k_generate", "fields": "k_generate<read only>", "txbuild": "k_tx_build_wave<MODE_L3>", "tximix": "k_tx_build<MODE_L3>", "eth1514": "k_verify<MODE_L2>"}.get(op, "k_ipv4_validate_rows" if kind == unet_amd.SYNTH_IPV4_HDR20 else "k_verify<MODE_L3>")
     torch.cuda.synchronize()
 
     # ---- timed region

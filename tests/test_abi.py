@@ -63,8 +63,13 @@ def test_records_per_wave_rule():
 
 def test_tx_packets_per_wave_rule():
     tpw = _ffi.tx_packets_per_wave
-    assert [tpw(0), tpw(18), tpw(112), tpw(113), tpw(599), tpw(600), tpw(1024), tpw(1025)] == [64, 64, 64, 32, 32, 16, 16, 8]
-    assert [tpw(1472), tpw(2499), tpw(2500), tpw(4999), tpw(5000), tpw(7999), tpw(8000), tpw(8972), tpw(65507)] == [8, 8, 4, 4, 2, 2, 1, 1, 1]
+    assert [tpw(0), tpw(18), tpw(112), tpw(113), tpw(599), tpw(600), tpw(1024), tpw(1025)] == [64, 64, 64, 32, 32, 16, 16, 1]
+    assert [tpw(1472), tpw(2500), tpw(8972), tpw(65507)] == [1, 1, 1, 1]
+    # above 1 KiB of mean payload: one packet per wavefront, or per group of wavefronts -- about three 1 KiB rows of output each
+    wpp = _ffi.tx_waves_per_packet
+    assert [wpp(0), wpp(1024), wpp(1025), wpp(1472), wpp(3044), wpp(3045), wpp(6116), wpp(6117)] == [1, 1, 1, 1, 1, 2, 2, 4]
+    assert [wpp(12260), wpp(12261), wpp(24548), wpp(24549), wpp(65507)] == [4, 8, 8, 16, 16]
+    assert [wpp(3030, 1), wpp(3031, 1), wpp(6102, 1), wpp(6103, 1)] == [1, 2, 2, 4]   # Ethernet output: 14 bytes more per packet
 
 
 def test_tx_layout_aligned_matches_python_and_rejects_bad_alignment():

@@ -28,7 +28,7 @@ def put(src, dst):
 
 
 kern = {"udp1500": "k_verify", "imix": "k_verify", "odd": "k_verify", "hdr20": "k_ipv4_validate_rows", "csum": "k_csum", "generate": "k_generate",
-        "txbuild": "k_tx_build", "tximix": "k_tx_build"}
+        "txbuild": "k_tx_build_wave", "tximix": "k_tx_build<"}
 t = {}
 try:
     t = json.load(open("profiles/traffic.json"))

@@ -74,6 +74,42 @@ __global__ __launch_bounds__(256) void k_single_loop(const u32x4* __restrict__ s
     }
 }
 
+// Records of up to 4 W chunks, 64 / W of them per step, one per group of W lanes (lane `sub` of a group moves chunks
+// sub, sub + W, sub + 2 W, sub + 3 W); `steps` steps per wave, the next step's loads requested before the current
+// step's stores.
+template <u32 W>
+__global__ __launch_bounds__(256) void k_groups(const u32x4* __restrict__ src, u32x4* __restrict__ dst, u32 n, u32 P, u32 IS, u32 OS,
+                                                u32 steps) {
+    const u32 lane = threadIdx.x & 63u, sub = lane & (W - 1u), g = lane / W;
+    constexpr u32 per = 64u / W;
+    const u32 w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    u32 rec = w * per * steps + g;
+    const u32 last = P - 1u;
+    u32x4 v[4], nv[4];
+    {
+        const u32x4* p = src + (u64)min(rec, n - 1u) * IS;
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) v[j] = __builtin_nontemporal_load(p + min(sub + j * W, last));
+    }
+    for (u32 s = 0; s < steps; ++s) {
+        const u32 nrec = rec + per;
+        if (s + 1u < steps) {
+            const u32x4* p = src + (u64)min(nrec, n - 1u) * IS;
+#pragma unroll
+            for (u32 j = 0; j < 4; ++j) nv[j] = __builtin_nontemporal_load(p + min(sub + j * W, last));
+        }
+        if (rec < n) {
+            u32x4* q = dst + (u64)rec * OS;
+#pragma unroll
+            for (u32 j = 0; j < 4; ++j)
+                if (sub + j * W < P) q[sub + j * W] = v[j];
+        }
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) v[j] = nv[j];
+        rec = nrec;
+    }
+}
+
 template <typename F>
 double timeit(F f, int iters) {
     hipEvent_t a, b;
@@ -134,6 +170,25 @@ int main() {
             printf("\n");
             fflush(stdout);
         }
+    }
+    // mid-size and short records by lane groups: one step per wave against loops
+    struct GCase { u32 W, P; };
+    const GCase gcases[] = {{16, 36}, {16, 64}, {16, 52}, {8, 18}, {8, 32}, {4, 10}, {4, 16}, {4, 6}};
+    for (const GCase& c : gcases) {
+        const u32 n = (u32)((nchunks - 64) / c.P);
+        const double moved = 2.0 * n * c.P * 16.0;
+        printf("groups of %2u lanes, records of %2u chunks packed:", c.W, c.P);
+        for (u32 steps : {1u, 2u, 4u, 8u}) {
+            const u32 per_wave = 64u / c.W * steps;
+            const u32 waves = (n + per_wave - 1) / per_wave;
+            double ms = 0;
+            if (c.W == 16) ms = timeit([&] { hipLaunchKernelGGL(k_groups<16>, dim3((waves + 3) / 4), dim3(256), 0, 0, (const u32x4*)s, (u32x4*)d, n, c.P, c.P, c.P, steps); }, 6);
+            if (c.W == 8) ms = timeit([&] { hipLaunchKernelGGL(k_groups<8>, dim3((waves + 3) / 4), dim3(256), 0, 0, (const u32x4*)s, (u32x4*)d, n, c.P, c.P, c.P, steps); }, 6);
+            if (c.W == 4) ms = timeit([&] { hipLaunchKernelGGL(k_groups<4>, dim3((waves + 3) / 4), dim3(256), 0, 0, (const u32x4*)s, (u32x4*)d, n, c.P, c.P, c.P, steps); }, 6);
+            printf("  %u step%s/wave %7.1f", steps, steps > 1 ? "s" : "", moved / ms / 1e6);
+        }
+        printf(" GB/s\n");
+        fflush(stdout);
     }
     return 0;
 }

@@ -164,6 +164,7 @@ _SIGS = {
     "unet_hint_mean_len": (C.c_int, [_vp, C.c_uint32]),
     "unet_records_per_wave": (C.c_int, [C.c_uint32, C.c_uint32]),
     "unet_tx_packets_per_wave": (C.c_int, [C.c_uint32]),
+    "unet_tx_waves_per_packet": (C.c_int, [C.c_uint32, C.c_int]),
     "unet_generate_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, _u8p]),
     "unet_checksum_fields_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, _vp, _u8p]),
     "unet_generate": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, _u8p]),
@@ -272,6 +273,11 @@ def records_per_wave(mean_len: int, max_len: int = 0) -> int:
 def tx_packets_per_wave(mean_payload_len: int) -> int:
     """Packets one wavefront builds for a batch of this mean payload length."""
     return int(load_library().unet_tx_packets_per_wave(int(mean_payload_len)))
+
+
+def tx_waves_per_packet(mean_payload_len: int, mode: int = 0) -> int:
+    """Wavefronts that share one packet of a batch of this mean payload length (1 up to 1 KiB and for packets of up to three rows)."""
+    return int(load_library().unet_tx_waves_per_packet(int(mean_payload_len), int(mode)))
 
 
 def synth_len(kind: int, seed: int, idx: int) -> int:

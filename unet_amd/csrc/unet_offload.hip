@@ -534,7 +534,10 @@ int unet_hint_mean_len(unet_ctx* c, uint32_t mean_len) {
 }
 
 int unet_records_per_wave(uint32_t mean_len, uint32_t max_len) { return tile_for(mean_len, max_len != 0, max_len); }
-int unet_tx_packets_per_wave(uint32_t mean_payload_len) { return tx_tile_for(mean_payload_len); }
+int unet_tx_packets_per_wave(uint32_t mean_payload_len) { return mean_payload_len > 1024 ? 1 : tx_tile_for(mean_payload_len); }
+int unet_tx_waves_per_packet(uint32_t mean_payload_len, int mode) {
+    return mean_payload_len > 1024 ? 1 << tx_group_log2_for(mean_payload_len, mode == UNET_MODE_L2) : 1;
+}
 
 int unet_device_count(void) {
     int n = 0;
