@@ -316,6 +316,71 @@ def test_tx_build_may_fill_each_packets_last_line(offload, mode, align16):
     assert filled > 0  # the permission is used
 
 
+def _check_against_oracle(got, got_len, got_status, exp, exp_len, exp_status, ooff, obytes, fill=0xAB):
+    """Packet bytes equal the oracle's, the pad up to each packet's 16-byte boundary is zero, every other byte of the
+    buffer (slots of refused packets, gaps, what lies in front of the first packet and behind out_arena_bytes) keeps its fill."""
+    assert (got_status == exp_status).all() and (got_len == exp_len).all()
+    ok = exp_status == 0
+    m = _valid_mask(obytes, ooff[ok], exp_len[ok])
+    bad = np.flatnonzero(got[:obytes][m] != exp[m])
+    assert bad.size == 0, bad[:4]
+    slots = _valid_mask(obytes, ooff[ok], (exp_len[ok] + 15) // 16 * 16)
+    assert (got[:obytes][slots & ~m] == 0).all()
+    assert (got[:obytes][~slots] == fill).all() and (got[obytes:] == fill).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [unet_amd.MODE_L3, unet_amd.MODE_L2])
+def test_tx_build_tiles_of_short_packets_staged_in_lds(offload, mode):
+    """Tiles whose packets lie back to back in the output arena are assembled in LDS and leave as whole rows: uniform
+    lengths on both sides of every limit (one lane up to 48 or 80 bytes, groups of 4 / 8 / 16 lanes, what the staging
+    area of 64-, 32- and 16-packet tiles holds), output ranges that start on every chunk of a 128-byte line, batches
+    that end inside a tile -- and the tiles that must not take that route: a refused packet, a gap or a step back in
+    the output offsets, a long payload among the short ones."""
+    rng = np.random.default_rng(101 + mode)
+    ifc = unet_amd.Iface("192.0.2.2", "255.255.255.0", mac=bytes.fromhex("02aabbccddee"), mode=mode)
+
+    def run(lens, front=0, mutate=None):
+        desc, payloads = make_batch(rng, lens, ifc)
+        arena, off16, plen = unet_amd.pack_arena(payloads, pad_byte=0x77)
+        ooff, obytes = tx_out_layout(plen, mode)
+        ooff = ooff + np.uint32(front)
+        obytes += 16 * front
+        if mutate:
+            ooff, obytes = mutate(desc, ooff, obytes)
+        exp, exp_len, exp_status = O.tx_build_batch(arena, off16, plen, desc, ifc, ooff, obytes)
+        got, got_len, got_status = _gpu_build(offload, arena, off16, plen, desc, ifc, ooff, obytes)
+        _check_against_oracle(got, got_len, got_status, exp, exp_len, exp_status, ooff, obytes)
+        return got_status
+
+    for i, L in enumerate([0, 1, 15, 16, 17, 32, 33, 47, 48, 49, 54, 55, 64, 65, 80, 81, 84, 85, 100, 104, 116, 117, 128, 200,
+                           228, 229, 244, 245, 256, 320, 336, 337, 400, 548, 549, 564, 565, 580, 1000]):
+        run([L] * (64 * 3 + 7 + i % 5), front=i % 8)
+    for lo, hi, n in ((0, 49, 517), (0, 81, 518), (0, 90, 400), (20, 130, 300), (0, 250, 301), (100, 260, 203), (200, 565, 155), (330, 600, 99)):
+        run([int(x) for x in rng.integers(lo, hi, size=n)], front=int(rng.integers(0, 8)))
+
+    def refuse_some(desc, ooff, obytes):
+        desc["proto"][5::37] = 6
+        return ooff, obytes
+
+    def gap_and_step_back(desc, ooff, obytes):
+        ooff = ooff.copy()
+        k = len(ooff) // 2
+        ooff[k:] += 9                                     # a gap in front of packet k
+        tail = ooff[-1] + 40 - ooff[10]                   # packet 10 moves behind everything else: a step forth and back
+        ooff[10] += tail
+        return ooff, obytes + 16 * int(tail + 9 + 40)
+
+    for mut in (refuse_some, gap_and_step_back):
+        for L in (18, 64, 200, 400):
+            st = run([L] * 333, front=3, mutate=mut)
+            assert (st != 0).any() == (mut is refuse_some)
+    # a long payload among short ones: its tile takes the ordinary route, the others are staged
+    lens = [40] * 500
+    lens[70], lens[300] = 1500, 9000
+    run(lens, front=1)
+
+
 @pytest.mark.gpu
 def test_tx_build_fixed_stride_and_status(offload):
     rng = np.random.default_rng(3)

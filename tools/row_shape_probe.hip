@@ -110,6 +110,38 @@ __global__ __launch_bounds__(256) void k_groups(const u32x4* __restrict__ src, u
     }
 }
 
+// The same records by the same lane groups, `steps` steps per wave, but the copies go to LDS at their place in the
+// wave's output range first and leave as whole 1 KiB rows (streaming stores) once all of them are there.
+// LD: 0 = default-policy loads, 2 = non-temporal.
+template <u32 W, int LD>
+__global__ __launch_bounds__(256) void k_groups_staged(const u32x4* __restrict__ src, u32x4* __restrict__ dst, u32 n, u32 P, u32 steps) {
+    extern __shared__ u32x4 lds[];
+    const u32 lane = threadIdx.x & 63u, sub = lane & (W - 1u), g = lane / W, wv = threadIdx.x >> 6;
+    constexpr u32 per = 64u / W;
+    const u32 w = blockIdx.x * (blockDim.x >> 6) + wv;
+    const u32 per_wave = per * steps;
+    const u32 first = w * per_wave;
+    if (first >= n) return;
+    const u32 cnt = min(per_wave, n - first);
+    u32x4* area = lds + wv * (per_wave * P);
+    const u32 last = P - 1u;
+    for (u32 s = 0; s < steps; ++s) {
+        const u32 r = s * per + g;
+        const u32x4* p = src + (u64)min(first + r, n - 1u) * P;
+        u32x4 v[4];
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) v[j] = LD ? __builtin_nontemporal_load(p + min(sub + j * W, last)) : p[min(sub + j * W, last)];
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j)
+            if (r < cnt && sub + j * W < P) area[r * P + sub + j * W] = v[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const u32 span = cnt * P;
+    u32x4* q = dst + (u64)first * P;
+    for (u32 c = lane; c < span; c += 64u) __builtin_nontemporal_store(area[c], q + c);
+}
+
 template <typename F>
 double timeit(F f, int iters) {
     hipEvent_t a, b;
@@ -173,7 +205,7 @@ int main() {
     }
     // mid-size and short records by lane groups: one step per wave against loops
     struct GCase { u32 W, P; };
-    const GCase gcases[] = {{16, 36}, {16, 64}, {16, 52}, {8, 18}, {8, 32}, {4, 10}, {4, 16}, {4, 6}};
+    const GCase gcases[] = {{16, 36}, {16, 64}, {16, 52}, {8, 18}, {8, 32}, {4, 10}, {4, 16}, {4, 6}, {4, 3}};
     for (const GCase& c : gcases) {
         const u32 n = (u32)((nchunks - 64) / c.P);
         const double moved = 2.0 * n * c.P * 16.0;
@@ -186,6 +218,22 @@ int main() {
             if (c.W == 8) ms = timeit([&] { hipLaunchKernelGGL(k_groups<8>, dim3((waves + 3) / 4), dim3(256), 0, 0, (const u32x4*)s, (u32x4*)d, n, c.P, c.P, c.P, steps); }, 6);
             if (c.W == 4) ms = timeit([&] { hipLaunchKernelGGL(k_groups<4>, dim3((waves + 3) / 4), dim3(256), 0, 0, (const u32x4*)s, (u32x4*)d, n, c.P, c.P, c.P, steps); }, 6);
             printf("  %u step%s/wave %7.1f", steps, steps > 1 ? "s" : "", moved / ms / 1e6);
+        }
+        printf(" GB/s\n");
+        printf("   ... staged through LDS, rows out:              ");
+        for (u32 steps : {1u, 2u, 4u, 8u}) {
+            const u32 per_wave = 64u / c.W * steps;
+            if (per_wave * c.P * 16u * 4u > 64u * 1024u) { printf("  %u steps       -", steps); continue; }
+            const u32 waves = (n + per_wave - 1) / per_wave;
+            const u32 shm = per_wave * c.P * 16u * 4u;
+            double ms = 0, ms0 = 0;
+            if (c.W == 16) { ms = timeit([&] { hipLaunchKernelGGL((k_groups_staged<16, 2>), dim3((waves + 3) / 4), dim3(256), shm, 0, (const u32x4*)s, (u32x4*)d, n, c.P, steps); }, 6);
+                             ms0 = timeit([&] { hipLaunchKernelGGL((k_groups_staged<16, 0>), dim3((waves + 3) / 4), dim3(256), shm, 0, (const u32x4*)s, (u32x4*)d, n, c.P, steps); }, 6); }
+            if (c.W == 8) { ms = timeit([&] { hipLaunchKernelGGL((k_groups_staged<8, 2>), dim3((waves + 3) / 4), dim3(256), shm, 0, (const u32x4*)s, (u32x4*)d, n, c.P, steps); }, 6);
+                            ms0 = timeit([&] { hipLaunchKernelGGL((k_groups_staged<8, 0>), dim3((waves + 3) / 4), dim3(256), shm, 0, (const u32x4*)s, (u32x4*)d, n, c.P, steps); }, 6); }
+            if (c.W == 4) { ms = timeit([&] { hipLaunchKernelGGL((k_groups_staged<4, 2>), dim3((waves + 3) / 4), dim3(256), shm, 0, (const u32x4*)s, (u32x4*)d, n, c.P, steps); }, 6);
+                            ms0 = timeit([&] { hipLaunchKernelGGL((k_groups_staged<4, 0>), dim3((waves + 3) / 4), dim3(256), shm, 0, (const u32x4*)s, (u32x4*)d, n, c.P, steps); }, 6); }
+            printf("  %u steps nt %6.1f / default %6.1f", steps, moved / ms / 1e6, moved / ms0 / 1e6);
         }
         printf(" GB/s\n");
         fflush(stdout);

@@ -14,7 +14,7 @@ import torch
 import unet_amd
 from unet_amd._ffi import TX_DESC_DTYPE, tx_frame_len, tx_out_layout
 
-KNOBS = ("UNET_TX_WAVE", "UNET_TXW_GROUP", "UNET_TXW_BLOCK", "UNET_TXW_POLICY", "UNET_TX_TILE")
+KNOBS = ("UNET_TX_WAVE", "UNET_TXW_GROUP", "UNET_TXW_BLOCK", "UNET_TXW_POLICY", "UNET_TX_TILE", "UNET_TX_STAGE")
 configs = []
 for item in sys.argv[1].split(";"):
     name, _, kv = item.partition("=")

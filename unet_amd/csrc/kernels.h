@@ -13,6 +13,7 @@ namespace unetdev {
 #endif
 constexpr u32 kBlock = UNET_BLOCK;  // 4 waves
 constexpr u32 kTxFillLines = 1;  // = UNET_TX_FILL_LINES of the C header
+constexpr u32 kTxNoStage = 1u << 16;  // internal flag of k_tx_build (UNET_TX_STAGE=0 in the environment): no output staging, for A/B runs
 constexpr u32 UNET_TX_OK_ = 0, UNET_TX_E_PROTO_ = 1, UNET_TX_E_TOO_LONG_ = 2, UNET_TX_E_RANGE_ = 3;  // = UNET_TX_* of the C header
 constexpr u32 kMaxLen = 65535;   // IPv4 maximum (src/protocols/ipv4.rs:18), loopback MTU (src/devices/loopback.rs:16)
 
@@ -74,6 +75,9 @@ __device__ unsigned int g_lds_out_of_area = 0;
 #endif
 #ifndef UNET_TX_MID_PATH
 #define UNET_TX_MID_PATH 1    // k_tx_build: lane groups for packets of up to 64 chunks
+#endif
+#ifndef UNET_TX_STAGE
+#define UNET_TX_STAGE 1       // k_tx_build: tiles of short packets that lie back to back in the output arena are assembled in LDS and stored as whole rows
 #endif
 #ifndef UNET_TX_G4
 #define UNET_TX_G4 1          // k_tx_build: groups of 4 lanes for packets of up to 16 chunks
@@ -1290,6 +1294,39 @@ struct TxRows {
 // payloads; streaming stores of partial lines: 3.5 TB/s there and 0.7 TB/s on 128-byte payloads).
 __device__ __forceinline__ void tx_store_small(u32x4 v, u32x4* p) { *p = v; }
 
+// Where the single-lane and lane-group paths put a packet's output chunk m: into the output arena, or -- when the tile's
+// packets lie back to back there and fit the wave's staging area -- into LDS at the chunk's place in the tile's output
+// range, which then leaves as whole 1 KiB rows (tx_flush_staged).  `staged` is wave-uniform.
+struct TxSink {
+    uint8_t* out_arena;
+    u32x4* area;   // LDS
+    u32 base;      // first chunk of the staged range (on a 128-byte line)
+    u32 limit;     // chunks the area holds
+    bool staged;
+    __device__ __forceinline__ void store(u32 oslot, u32 m, u32x4 v) const {
+        if (staged) UNET_LDS_STORE(area, oslot - base + m, limit, v);
+        else tx_store_small(v, reinterpret_cast<u32x4*>(out_arena + (u64)oslot * 16u) + m);
+    }
+};
+
+// Chunks [lead, span) of the staged range, row by row: whole lines with streaming stores, the range's first and last
+// line -- shared with the neighbouring tiles when they start or end inside them -- with the default policy.
+__device__ __forceinline__ void tx_flush_staged(const TxSink& k, u32 lane, u32 lead, u32 span) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    u32x4* q = reinterpret_cast<u32x4*>(k.out_arena + (u64)k.base * 16u);
+    const u32 last_line = (span - 1u) >> 3;
+    const bool cut_first = lead != 0u, cut_last = (span & 7u) != 0u;
+#pragma nounroll
+    for (u32 c = lane; c < span; c += kWave) {
+        if (c < lead) continue;
+        const u32x4 v = k.area[c];
+        const u32 line = c >> 3;
+        if ((cut_first && line == 0u) || (cut_last && line == last_line)) q[c] = v;
+        else tx_store(v, q + c);
+    }
+}
+
 // Rows 0/1 of a payload, loaded SH lanes to the right: lane L holds payload chunk L - SH (row 0) and
 // L + 64 - SH (row 1), so that lane L ends up owning output chunk L (L + 64) of the packet.  Exactly two
 // unconditional, clamped load instructions, as in issue_rows.
@@ -1439,33 +1476,41 @@ __device__ __forceinline__ void tx_build_one(const TxRows& cur, u32 lane, u32 fr
     tx_finish<R, SH>(t, lane, a, c, fx, fy, wave_sum(acc), hdr, l4_partial_be, udp);
 }
 
-// A packet with a payload of at most 3 chunks (48 bytes: measured break-even with the 4-lane groups), built
-// by its own lane: the same virtual-chunk splice as tx_build_one, with every chunk of the packet in this
-// lane's registers.
+// A packet with a short payload, built by its own lane: the same virtual-chunk splice as tx_build_one, with every
+// chunk of the packet in this lane's registers.  Up to 3 chunks (48 bytes) when the lane stores its chunks into the
+// output arena itself -- the measured break-even with the 4-lane groups, whose stores fill lines better --, up to 5
+// (80 bytes) when the tile's output is staged in LDS (64-byte payloads: 5.1 -> 5.8 TB/s against the groups).
+// max_chunks (wave-uniform): the longest such payload of the tile; chunks past the third are only requested if some
+// lane has them (18-byte payloads run 9 % slower with five unconditional loads).
 constexpr u32 kTxSmallChunks = 3;
+constexpr u32 kTxSmallStaged = 5;
 
 template <int R, u32 SH>
-__device__ __forceinline__ void tx_build_small(const Batch& pay, u32 my_len, u32 my_slot, u32 frame_len,
-                                               u32x4* __restrict__ pout, const u32x4* __restrict__ hdr, u32 l4_partial_be,
-                                               bool udp) {
+__device__ __forceinline__ void tx_build_small(const Batch& pay, u32 my_len, u32 my_slot, u32 frame_len, const TxSink& sink,
+                                               u32 my_oslot, const u32x4* __restrict__ hdr, u32 l4_partial_be, bool udp,
+                                               u32 max_chunks) {
+    constexpr u32 N = kTxSmallStaged;
     const u32 nin = (my_len + 15u) >> 4, last = nin != 0u ? nin - 1u : 0u;
     const u32 nout = (frame_len + 15u) >> 4;
     // an empty payload may sit at the very end of the arena: read the arena's first chunk instead
     const u32x4* p = reinterpret_cast<const u32x4*>(pay.arena + (nin != 0u ? (u64)my_slot * 16u : 0ull));
-    u32x4 v[SH + kTxSmallChunks + 1u];
+    u32x4 v[SH + N + 1u];
 #pragma unroll
-    for (u32 k = 0; k < kTxSmallChunks; ++k) v[SH + k] = p[min(k, last)];
+    for (u32 k = 0; k < N; ++k) {
+        v[SH + k] = u32x4{0, 0, 0, 0};
+        if (k < kTxSmallChunks || k < max_chunks) v[SH + k] = p[min(k, last)];
+    }
     const LaneTail lt(my_len);
     const bool partial = (my_len & 15u) != 0u;
     u32 acc = 0;
 #pragma unroll
-    for (u32 k = 0; k < kTxSmallChunks; ++k) {
+    for (u32 k = 0; k < N; ++k) {
         u32x4 x = zero_unless(v[SH + k], k < nin);
         if (partial && k == last) x = lt.apply(x);
         v[SH + k] = x;
         acc = sum_chunk(x, acc);
     }
-    v[SH + kTxSmallChunks] = u32x4{0, 0, 0, 0};
+    v[SH + N] = u32x4{0, 0, 0, 0};
 #pragma unroll
     for (u32 c = 0; c < SH; ++c) v[c] = hdr[c];
     const u32 pay_be = bswap16(fold16(acc));
@@ -1473,8 +1518,8 @@ __device__ __forceinline__ void tx_build_small(const Batch& pay, u32 my_len, u32
     v[SH - 1u].w |= udp ? ck : 0u;
     v[SH - 1u].z |= udp ? 0u : ck;
 #pragma unroll
-    for (u32 c = 0; c < SH + kTxSmallChunks; ++c)
-        if (c < nout) tx_store_small(splice<R>(v[c], v[c + 1u]), pout + c);
+    for (u32 c = 0; c < SH + N; ++c)
+        if (c < nout) sink.store(my_oslot, c, splice<R>(v[c], v[c + 1u]));
 }
 
 // Packets of at most 4*W chunks (payloads of up to 4*W - SH chunks), 64/W at a time, one per group of W
@@ -1523,8 +1568,7 @@ __device__ __forceinline__ u32 from_next_in_group(u32 v, u32 nxt, bool last_of_g
 }
 
 template <u32 W, int R, u32 SH>
-__device__ __forceinline__ void consume_tx_step(const TxRowStep& g, u32 lane, uint8_t* __restrict__ out_arena,
-                                                const u32x4* __restrict__ park) {
+__device__ __forceinline__ void consume_tx_step(const TxRowStep& g, u32 lane, const TxSink& sink, const u32x4* __restrict__ park) {
     const u32 sub = lane & (W - 1u);
     const u32 nin = g.row_live ? (g.len + 15u) >> 4 : 0u, last = nin != 0u ? nin - 1u : 0u;
     const u32 nout = g.row_live ? (g.flen + 15u) >> 4 : 0u;
@@ -1560,7 +1604,6 @@ __device__ __forceinline__ void consume_tx_step(const TxRowStep& g, u32 lane, ui
     const bool ck_lane = sub == SH - 1u;
     x0.w |= ck_lane && g.udp ? ck : 0u;
     x0.z |= ck_lane && !g.udp ? ck : 0u;
-    u32x4* pout = reinterpret_cast<u32x4*>(out_arena + (u64)g.oslot * 16u);
     const bool last_of_group = sub == W - 1u;
 #define UNET_TXM_EMIT(X, NX, NY, I)                                                      \
     {                                                                                    \
@@ -1568,7 +1611,7 @@ __device__ __forceinline__ void consume_tx_step(const TxRowStep& g, u32 lane, ui
         h_.x = from_next_in_group<W>(X.x, NX, last_of_group);                            \
         if (R > 4) h_.y = from_next_in_group<W>(X.y, NY, last_of_group);                 \
         const u32 m_ = W * (I) + sub;                                                    \
-        if (m_ < nout) tx_store_small(splice<R>(X, h_), pout + m_);                      \
+        if (m_ < nout) sink.store(g.oslot, m_, splice<R>(X, h_));                        \
     }
     UNET_TXM_EMIT(x0, x1.x, x1.y, 0u)
     UNET_TXM_EMIT(x1, x2.x, x2.y, 1u)
@@ -1579,8 +1622,8 @@ __device__ __forceinline__ void consume_tx_step(const TxRowStep& g, u32 lane, ui
 
 template <u32 W, int R, u32 SH>
 __device__ __forceinline__ void tx_rows_path(const Batch& pay, const Tile& t, bool mine_here, u32 my_flen, u32 my_oslot,
-                                             u32 my_partial, bool my_udp, u32* __restrict__ list,
-                                             uint8_t* __restrict__ out_arena, const u32x4* __restrict__ park) {
+                                             u32 my_partial, bool my_udp, u32* __restrict__ list, const TxSink& sink,
+                                             const u32x4* __restrict__ park) {
     constexpr u32 kPerStep = kWave / W;
     const u64 mask = __ballot(mine_here);
     if (mask == 0ull) return;
@@ -1594,11 +1637,11 @@ __device__ __forceinline__ void tx_rows_path(const Batch& pay, const Tile& t, bo
 #pragma nounroll
     while (true) {
         g1 = issue_tx_step<W, SH>(pay, t, my_flen, my_oslot, my_partial, my_udp, list, next, count);
-        consume_tx_step<W, R, SH>(g0, t.lane, out_arena, park);
+        consume_tx_step<W, R, SH>(g0, t.lane, sink, park);
         if (next >= count) break;
         next += kPerStep;
         g0 = issue_tx_step<W, SH>(pay, t, my_flen, my_oslot, my_partial, my_udp, list, next, count);
-        consume_tx_step<W, R, SH>(g1, t.lane, out_arena, park);
+        consume_tx_step<W, R, SH>(g1, t.lane, sink, park);
         if (next >= count) break;
         next += kPerStep;
     }
@@ -1682,7 +1725,13 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx
     constexpr u32 SH = MODE == MODE_L2 ? 3u : 2u;    // output chunks that contain header bytes
     constexpr int R = MODE == MODE_L2 ? 6 : 4;       // payload bytes inside the last header chunk
     static_assert(16u * SH - H == (u32)R, "header geometry");
-    constexpr u32 kWaveLds = TILE * SH + (TILE + 3u) / 4u;  // header chunks, then one list entry per packet
+    // Staging area for the output of tiles of short packets (UNET_TX_STAGE): whatever is left of 10 KiB per wave, so
+    // that four workgroups still share a CU's 160 KiB of LDS (three measured 10-20 % slower on every short size, staged
+    // or not): 432-604 chunks, e.g. 64 packets of up to six or seven chunks, 32 of up to sixteen, 16 of up to 36
+    // (548-byte payloads), less the seven chunks the range may start inside its line.
+    constexpr u32 kWaveBudget = 640;  // chunks
+    constexpr u32 kStage = UNET_TX_STAGE && TILE >= 16 ? kWaveBudget - TILE * SH - (TILE + 3u) / 4u : 0u;
+    constexpr u32 kWaveLds = TILE * SH + (TILE + 3u) / 4u + kStage;  // header chunks, one list entry per packet, staged output
     __shared__ u32x4 lds[(kBlock / kWave) * kWaveLds];
     u32x4* park = lds + (threadIdx.x >> 6) * kWaveLds;
     u32* list = reinterpret_cast<u32*>(park + TILE * SH);
@@ -1713,13 +1762,11 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx
         const u32 upto = (end + 7u) & ~7u;
         if (upto >= end && (u64)upto * 16u <= out_bytes) store_len = (upto - my_oslot) * 16u;
     }
-    const bool my_small = UNET_TX_SMALL_PATH && my_go && t.my_len <= 16u * kTxSmallChunks;
-    // payloads of up to 4*W - SH chunks: the packet fits the four steps of a group of W lanes
-    const bool my_mid = UNET_TX_MID_PATH && my_go && !my_small && t.my_len <= 16u * (kWave - SH);
-    const bool my_g4 = UNET_TX_G4 && my_mid && t.my_len <= 16u * (16u - SH);
-    const bool my_g8 = my_mid && !my_g4 && t.my_len <= 16u * (32u - SH);
+    // payloads of up to 4*W - SH chunks fit the four steps of a group of W lanes; up to three chunks, one lane
+    const bool fits_groups = UNET_TX_MID_PATH && my_go && t.my_len <= 16u * (kWave - SH);
+    const bool small3 = UNET_TX_SMALL_PATH && my_go && t.my_len <= 16u * kTxSmallChunks;
 
-    u64 todo = __ballot(my_go && !my_small && !my_mid);
+    u64 todo = __ballot(my_go && !small3 && !fits_groups);
     constexpr int D = UNET_TX_DEPTH;  // register buffers in rotation: D - 1 payloads' loads in flight while one packet is built
     TxRows buf[D];
 #define UNET_NEXT(X)                                                                 \
@@ -1730,7 +1777,29 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx
         X = issue_rows_shifted<SH>(pay, t.my_len, t.my_slot, t.lane, j, has);        \
     }
     const bool any = todo != 0ull;
+    // Output staging: every packet of the tile is built by one lane or a lane group, and their output chunks lie back to
+    // back in the arena (any packed layout) within the staging area's size.
+    TxSink sink{out_arena, park + TILE * SH + (TILE + 3u) / 4u, 0u, kStage, false};
+    u32 stage_lead = 0, stage_span = 0;
+    const bool short_if_staged = UNET_TX_SMALL_PATH && my_go && t.my_len <= 16u * kTxSmallStaged;
+    if (kStage != 0u && !any && (flags & kTxNoStage) == 0u) {
+        const u32 my_cover = ((short_if_staged ? frame_len : store_len) + 15u) >> 4;  // chunks this packet's stores cover
+        const bool in = t.lane < t.cnt, is_last = t.lane + 1u >= t.cnt;
+        const u32 next_oslot = from_next_lane(my_oslot, 0xffffffffu);
+        if (__ballot(!in || (my_go && (is_last || my_oslot + my_cover == next_oslot))) == ~0ull) {
+            const u32 lo = rdlane(my_oslot, 0u), end = rdlane(my_oslot + my_cover, t.cnt - 1u);
+            sink.base = lo & ~7u;
+            stage_lead = lo & 7u;
+            stage_span = end - sink.base;
+            sink.staged = stage_span <= kStage;
+        }
+    }
+    const bool my_small = sink.staged ? short_if_staged : small3;
+    const bool my_mid = fits_groups && !my_small;
+    const bool my_g4 = UNET_TX_G4 && my_mid && t.my_len <= 16u * (16u - SH);
+    const bool my_g8 = my_mid && !my_g4 && t.my_len <= 16u * (32u - SH);
     const u64 mid_mask = __ballot(my_mid);
+    const u32 small_chunks = __ballot(my_small && t.my_len > 64u) != 0ull ? 5u : (__ballot(my_small && t.my_len > 48u) != 0ull ? 4u : 3u);
 #ifndef UNET_TX_EARLY_BIG
 #define UNET_TX_EARLY_BIG 0   // k_tx_build: the first whole-wave payloads are requested ahead of the lane-group and single-lane packets too
 #endif
@@ -1758,9 +1827,9 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx
     // ---- mid-size payloads, 16, 8 or 4 packets at a time (the register buffers are free again afterwards)
     if (mid_mask != 0ull) {
         // (a group of W lanes covers 4 W chunks, a multiple of eight: the filled-up length still fits)
-        if (UNET_TX_G4) tx_rows_path<4, R, SH>(pay, t, my_g4, store_len, my_oslot, my_partial, my_udp, list, out_arena, park);
-        tx_rows_path<8, R, SH>(pay, t, my_g8, store_len, my_oslot, my_partial, my_udp, list, out_arena, park);
-        tx_rows_path<16, R, SH>(pay, t, my_mid && !my_g4 && !my_g8, store_len, my_oslot, my_partial, my_udp, list, out_arena, park);
+        if (UNET_TX_G4) tx_rows_path<4, R, SH>(pay, t, my_g4, store_len, my_oslot, my_partial, my_udp, list, sink, park);
+        tx_rows_path<8, R, SH>(pay, t, my_g8, store_len, my_oslot, my_partial, my_udp, list, sink, park);
+        tx_rows_path<16, R, SH>(pay, t, my_mid && !my_g4 && !my_g8, store_len, my_oslot, my_partial, my_udp, list, sink, park);
         if (any && !UNET_TX_EARLY_BIG) {
 #pragma unroll
             for (int k = 0; k < D - 1; ++k) UNET_NEXT(buf[k])
@@ -1769,8 +1838,8 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx
 
     // ---- short payloads: one packet per lane
     if (my_small)
-        tx_build_small<R, SH>(pay, t.my_len, t.my_slot, frame_len, reinterpret_cast<u32x4*>(out_arena + (u64)my_oslot * 16u),
-                              park + t.lane * SH, my_partial, my_udp);
+        tx_build_small<R, SH>(pay, t.my_len, t.my_slot, frame_len, sink, my_oslot, park + t.lane * SH, my_partial, my_udp, small_chunks);
+    if (sink.staged) tx_flush_staged(sink, t.lane, stage_lead, stage_span);
 
     // ---- three register buffers in rotation, as in tile_sums: the loads of the next two payloads are
     // in flight while one packet is assembled and stored

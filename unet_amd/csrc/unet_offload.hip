@@ -201,6 +201,7 @@ struct unet_ctx {
     int tx_wave = 1;              // UNET_TX_WAVE: 0 = every batch goes through the tile kernel, 2 = every batch one packet per wave (A/B, tests)
     u32 tx_wave_block = 256;      // UNET_TXW_BLOCK: threads per workgroup of k_tx_build_wave (64, 128 or 256; more when a packet's group of waves needs it)
     int tx_wave_policy = -1;      // UNET_TXW_POLICY (experiments): cache policy of the two row loads of k_tx_build_wave instead of the choice by mean payload
+    bool tx_stage = true;         // UNET_TX_STAGE=0: k_tx_build stores every packet straight into the output arena (A/B)
     int tx_group_log2 = -1;       // UNET_TXW_GROUP (1, 2, 4, 8, 16): waves per packet of k_tx_build_wave instead of the choice by mean payload
     bool hdr_plain = false;       // UNET_HDR_PLAIN, read once at unet_open
     u32 lds_pad = 0;              // UNET_LDS_PAD: bytes of unused LDS added to every workgroup of the record kernels (experiments: fewer resident workgroups)
@@ -350,14 +351,16 @@ inline int tx_tile_long(u64 mean_payload) {
     return mean_payload < 8000 ? 2 : 1;
 }
 
-// Packets per wave of k_tx_build by mean payload length.  Up to about 112 bytes (one lane or four to a packet) 64 --
-// 100 B 4.62 -> 5.01 TB/s against 32 (raw IP), 4.27 -> 4.54 (Ethernet); 128 B the same either way, 200 B better with 32.
-// From 600 bytes (16 lanes to a packet, four packets to a step) sixteen -- 640 B 5.39 -> 5.55 TB/s, 800 B 5.36 -> 5.57,
-// 960 B 5.12 -> 5.56, 1024 B 5.12 -> 5.32; below that 32 is as good or better.  Above 1 KiB see tx_tile_long.
+// Packets per wave of k_tx_build by mean payload length.  Up to 104 bytes (one lane or four to a packet) 64, up to 320
+// bytes 32, up to 1 KiB sixteen; above 1 KiB see tx_tile_long.  The steps follow what a wave's LDS staging area holds
+// (496-604 chunks of output: 64 packets of up to seven chunks, 32 of up to seventeen, 16 of up to 37) and what measured
+// best where staging does not apply: 100 B 64 against 32 per wave 5.01 / 4.62 TB/s, 128 B the same either way, 200 B
+// better with 32; 280 B 5.30 with 32 (not staged) against 5.22 with 16 (staged), 400 B 5.23 against 5.73, 640 B
+// 5.39 -> 5.55 with 16, 800 B 5.36 -> 5.57, 960 B 5.12 -> 5.56.
 inline int tx_tile_for(u64 mean_payload) {
     if (mean_payload > 1024) return tx_tile_long(mean_payload);
-    if (mean_payload >= 600) return 16;
-    return mean_payload <= 112 ? 64 : 32;
+    if (mean_payload > 320) return 16;
+    return mean_payload <= 104 ? 64 : 32;
 }
 
 // Waves per packet of k_tx_build_wave (as a power of two) by mean payload: about three rows of 64 output chunks per wave.
@@ -606,6 +609,7 @@ int unet_open(int device_id, unet_ctx** out_ctx) {
         const int v = atoi(t);
         c->tx_wave_block = v <= 64 ? 64u : (v <= 128 ? 128u : 256u);
     }
+    if (const char* t = getenv("UNET_TX_STAGE")) c->tx_stage = atoi(t) != 0;
     if (const char* t = getenv("UNET_TXW_POLICY")) c->tx_wave_policy = atoi(t);
     if (const char* t = getenv("UNET_TXW_GROUP")) {
         const int v = atoi(t);
@@ -1285,7 +1289,7 @@ int unet_tx_build_opts_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload
     const IfaceDev ifc = to_dev(iface);
 #define UNET_TX_LAUNCH(M, T)                                                                                             \
     hipLaunchKernelGGL((k_tx_build<M, T>), dim3(tiles_grid(n, b.tile_n)), dim3(kBlock), ctx->lds_pad, pick(ctx, stream), b, (const TxDesc*)d_desc, ifc, \
-                       d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status, flags)
+                       d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status, flags | (ctx->tx_stage ? 0u : kTxNoStage))
     const u64 mean_payload = pick_mean(ctx, payload_arena_bytes, payload_stride16, n);
     int tile = tx_tile_for(mean_payload);
     if (ctx->tx_tile_override) tile = ctx->tx_tile_override;
