@@ -1730,7 +1730,7 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx
     // or not): 432-604 chunks, e.g. 64 packets of up to six or seven chunks, 32 of up to sixteen, 16 of up to 36
     // (548-byte payloads), less the seven chunks the range may start inside its line.
     constexpr u32 kWaveBudget = 640;  // chunks
-    constexpr u32 kStage = UNET_TX_STAGE && TILE >= 16 ? kWaveBudget - TILE * SH - (TILE + 3u) / 4u : 0u;
+    constexpr u32 kStage = UNET_TX_STAGE && TILE >= 8 ? kWaveBudget - TILE * SH - (TILE + 3u) / 4u : 0u;
     constexpr u32 kWaveLds = TILE * SH + (TILE + 3u) / 4u + kStage;  // header chunks, one list entry per packet, staged output
     __shared__ u32x4 lds[(kBlock / kWave) * kWaveLds];
     u32x4* park = lds + (threadIdx.x >> 6) * kWaveLds;
