@@ -340,24 +340,30 @@ def test_tx_build_tiles_of_short_packets_staged_in_lds(offload, mode):
     rng = np.random.default_rng(101 + mode)
     ifc = unet_amd.Iface("192.0.2.2", "255.255.255.0", mac=bytes.fromhex("02aabbccddee"), mode=mode)
 
-    def run(lens, front=0, mutate=None):
+    def run(lens, front=0, mutate=None, fixed_stride=False):
         desc, payloads = make_batch(rng, lens, ifc)
-        arena, off16, plen = unet_amd.pack_arena(payloads, pad_byte=0x77)
+        if fixed_stride:  # (payloads of up to 1008 bytes at a fixed stride are staged whatever their mean length)
+            stride16 = max(1, (max(lens) + 15) // 16)
+            arena = rng.integers(0, 256, size=len(lens) * stride16 * 16, dtype=np.uint8)
+            off16, plen = None, np.asarray(lens, dtype=np.uint32)
+        else:
+            stride16 = 0
+            arena, off16, plen = unet_amd.pack_arena(payloads, pad_byte=0x77)
         ooff, obytes = tx_out_layout(plen, mode)
         ooff = ooff + np.uint32(front)
         obytes += 16 * front
         if mutate:
             ooff, obytes = mutate(desc, ooff, obytes)
-        exp, exp_len, exp_status = O.tx_build_batch(arena, off16, plen, desc, ifc, ooff, obytes)
-        got, got_len, got_status = _gpu_build(offload, arena, off16, plen, desc, ifc, ooff, obytes)
+        exp, exp_len, exp_status = O.tx_build_batch(arena, off16, plen, desc, ifc, ooff, obytes, pay_stride16=stride16)
+        got, got_len, got_status = _gpu_build(offload, arena, off16, plen, desc, ifc, ooff, obytes, stride16=stride16)
         _check_against_oracle(got, got_len, got_status, exp, exp_len, exp_status, ooff, obytes)
         return got_status
 
     for i, L in enumerate([0, 1, 15, 16, 17, 32, 33, 47, 48, 49, 54, 55, 64, 65, 80, 81, 84, 85, 100, 104, 116, 117, 128, 200,
                            228, 229, 244, 245, 256, 320, 336, 337, 400, 548, 549, 564, 565, 580, 1000]):
-        run([L] * (64 * 3 + 7 + i % 5), front=i % 8)
+        run([L] * (64 * 3 + 7 + i % 5), front=i % 8, fixed_stride=L > 320 or i % 2 == 1)
     for lo, hi, n in ((0, 49, 517), (0, 81, 518), (0, 90, 400), (20, 130, 300), (0, 250, 301), (100, 260, 203), (200, 565, 155), (330, 600, 99)):
-        run([int(x) for x in rng.integers(lo, hi, size=n)], front=int(rng.integers(0, 8)))
+        run([int(x) for x in rng.integers(lo, hi, size=n)], front=int(rng.integers(0, 8)), fixed_stride=hi > 320)
 
     def refuse_some(desc, ooff, obytes):
         desc["proto"][5::37] = 6
@@ -373,7 +379,7 @@ def test_tx_build_tiles_of_short_packets_staged_in_lds(offload, mode):
 
     for mut in (refuse_some, gap_and_step_back):
         for L in (18, 64, 200, 400):
-            st = run([L] * 333, front=3, mutate=mut)
+            st = run([L] * 333, front=3, mutate=mut, fixed_stride=L > 320)
             assert (st != 0).any() == (mut is refuse_some)
     # a long payload among short ones: its tile takes the ordinary route, the others are staged
     lens = [40] * 500

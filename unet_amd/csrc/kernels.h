@@ -1480,16 +1480,16 @@ __device__ __forceinline__ void tx_build_one(const TxRows& cur, u32 lane, u32 fr
 // chunk of the packet in this lane's registers.  Up to 3 chunks (48 bytes) when the lane stores its chunks into the
 // output arena itself -- the measured break-even with the 4-lane groups, whose stores fill lines better --, up to 5
 // (80 bytes) when the tile's output is staged in LDS (64-byte payloads: 5.1 -> 5.8 TB/s against the groups).
-// max_chunks (wave-uniform): the longest such payload of the tile; chunks past the third are only requested if some
-// lane has them (18-byte payloads run 9 % slower with five unconditional loads).
+// N: chunks the lane's registers hold (3 or 5); max_chunks (wave-uniform): the longest such payload of the tile --
+// chunks past the third are only requested if some lane has them (18-byte payloads run 9 % slower with five
+// unconditional loads), and a tile without them runs the three-chunk form (the IMIX payload mix 3 % faster).
 constexpr u32 kTxSmallChunks = 3;
 constexpr u32 kTxSmallStaged = 5;
 
-template <int R, u32 SH>
+template <int R, u32 SH, u32 N>
 __device__ __forceinline__ void tx_build_small(const Batch& pay, u32 my_len, u32 my_slot, u32 frame_len, const TxSink& sink,
                                                u32 my_oslot, const u32x4* __restrict__ hdr, u32 l4_partial_be, bool udp,
                                                u32 max_chunks) {
-    constexpr u32 N = kTxSmallStaged;
     const u32 nin = (my_len + 15u) >> 4, last = nin != 0u ? nin - 1u : 0u;
     const u32 nout = (frame_len + 15u) >> 4;
     // an empty payload may sit at the very end of the arena: read the arena's first chunk instead
@@ -1649,6 +1649,16 @@ __device__ __forceinline__ void tx_rows_path(const Batch& pay, const Tile& t, bo
     __builtin_amdgcn_wave_barrier();
 }
 
+// Chunks of LDS one wave of k_tx_build<MODE, TILE> has for staging its tile's output (0: that instantiation never
+// stages), and the dynamic LDS a launch that may stage needs.
+#ifndef UNET_TX_WAVE_BUDGET
+#define UNET_TX_WAVE_BUDGET 640
+#endif
+constexpr u32 tx_stage_chunks(int mode, int tile) {
+    return UNET_TX_STAGE && tile >= 8 ? (u32)UNET_TX_WAVE_BUDGET - (u32)tile * (mode == MODE_L2 ? 3u : 2u) - ((u32)tile + 3u) / 4u : 0u;
+}
+constexpr u32 tx_stage_bytes(int mode, int tile) { return (kBlock / kWave) * tx_stage_chunks(mode, tile) * 16u; }
+
 // The headers of one packet as its first SH virtual chunks (see tx_build_one): little-endian halves of the wire
 // bytes, R bytes to the right, the L4 checksum field still zero.  Returns the L4 checksum's partial sum (pseudo-header
 // and L4 header for UDP, the ICMP header otherwise) in the big-endian domain.
@@ -1727,12 +1737,14 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx
     static_assert(16u * SH - H == (u32)R, "header geometry");
     // Staging area for the output of tiles of short packets (UNET_TX_STAGE): whatever is left of 10 KiB per wave, so
     // that four workgroups still share a CU's 160 KiB of LDS (three measured 10-20 % slower on every short size, staged
-    // or not): 432-604 chunks, e.g. 64 packets of up to six or seven chunks, 32 of up to sixteen, 16 of up to 36
-    // (548-byte payloads), less the seven chunks the range may start inside its line.
-    constexpr u32 kWaveBudget = 640;  // chunks
-    constexpr u32 kStage = UNET_TX_STAGE && TILE >= 8 ? kWaveBudget - TILE * SH - (TILE + 3u) / 4u : 0u;
-    constexpr u32 kWaveLds = TILE * SH + (TILE + 3u) / 4u + kStage;  // header chunks, one list entry per packet, staged output
+    // or not): 432-622 chunks, e.g. 64 packets of up to six or seven chunks, 32 of up to sixteen, 16 of up to 36
+    // (548-byte payloads), less the seven chunks the range may start inside its line.  It lies in the launch's
+    // dynamic LDS (tx_stage_bytes; kTxNoStage and none of it for batches that are not expected to stage: a mix of
+    // IMIX payload sizes, whose tiles hardly ever qualify, runs 3 % slower with 40 KiB per workgroup reserved).
+    constexpr u32 kStage = tx_stage_chunks(MODE, TILE);
+    constexpr u32 kWaveLds = TILE * SH + (TILE + 3u) / 4u;  // header chunks, one list entry per packet
     __shared__ u32x4 lds[(kBlock / kWave) * kWaveLds];
+    extern __shared__ u32x4 lds_stage[];
     u32x4* park = lds + (threadIdx.x >> 6) * kWaveLds;
     u32* list = reinterpret_cast<u32*>(park + TILE * SH);
     Tile t;
@@ -1779,7 +1791,7 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx
     const bool any = todo != 0ull;
     // Output staging: every packet of the tile is built by one lane or a lane group, and their output chunks lie back to
     // back in the arena (any packed layout) within the staging area's size.
-    TxSink sink{out_arena, park + TILE * SH + (TILE + 3u) / 4u, 0u, kStage, false};
+    TxSink sink{out_arena, lds_stage + (threadIdx.x >> 6) * kStage, 0u, kStage, false};
     u32 stage_lead = 0, stage_span = 0;
     const bool short_if_staged = UNET_TX_SMALL_PATH && my_go && t.my_len <= 16u * kTxSmallStaged;
     if (kStage != 0u && !any && (flags & kTxNoStage) == 0u) {
@@ -1837,8 +1849,14 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx
     }
 
     // ---- short payloads: one packet per lane
-    if (my_small)
-        tx_build_small<R, SH>(pay, t.my_len, t.my_slot, frame_len, sink, my_oslot, park + t.lane * SH, my_partial, my_udp, small_chunks);
+    if (small_chunks > kTxSmallChunks) {  // (wave-uniform)
+        if (my_small)
+            tx_build_small<R, SH, kTxSmallStaged>(pay, t.my_len, t.my_slot, frame_len, sink, my_oslot, park + t.lane * SH, my_partial, my_udp,
+                                                  small_chunks);
+    } else if (my_small) {
+        tx_build_small<R, SH, kTxSmallChunks>(pay, t.my_len, t.my_slot, frame_len, sink, my_oslot, park + t.lane * SH, my_partial, my_udp,
+                                              kTxSmallChunks);
+    }
     if (sink.staged) tx_flush_staged(sink, t.lane, stage_lead, stage_span);
 
     // ---- three register buffers in rotation, as in tile_sums: the loads of the next two payloads are

@@ -1289,15 +1289,15 @@ int unet_tx_build_opts_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload
     Batch b{d_payload_arena, payload_arena_bytes, d_payload_off16, payload_stride16, d_payload_len, n};
     const IfaceDev ifc = to_dev(iface);
 #define UNET_TX_LAUNCH(M, T)                                                                                             \
-    hipLaunchKernelGGL((k_tx_build<M, T>), dim3(tiles_grid(n, b.tile_n)), dim3(kBlock), ctx->lds_pad, pick(ctx, stream), b, (const TxDesc*)d_desc, ifc, \
-                       d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status, flags | (ctx->tx_stage ? 0u : kTxNoStage))
+    hipLaunchKernelGGL((k_tx_build<M, T>), dim3(tiles_grid(n, b.tile_n)), dim3(kBlock), ctx->lds_pad + (stage ? tx_stage_bytes(M, T) : 0u), pick(ctx, stream), b, (const TxDesc*)d_desc, ifc, \
+                       d_out_arena, out_arena_bytes, d_out_off16, d_out_len, d_status, flags | (stage ? 0u : kTxNoStage))
     const u64 mean_payload = pick_mean(ctx, payload_arena_bytes, payload_stride16, n);
     int tile = tx_tile_for(mean_payload);
     if (ctx->tx_tile_override) tile = ctx->tx_tile_override;
     b.tile_n = (u32)tile;  // fewer packets per wave than the smallest instantiation: that kernel, part of its lanes
     // Long payloads (mean above 1 KiB): one packet per wave or group of waves, see k_tx_build_wave.  (A launch holds
     // fewer than 2^32 threads; a batch too large for that stays with the tile kernel.)
-    if (ctx->tx_wave == 2 || (ctx->tx_wave == 1 && !ctx->tx_tile_override && tile <= 8)) {
+    if (ctx->tx_wave == 2 || (ctx->tx_wave == 1 && !ctx->tx_tile_override && mean_payload > 1024)) {
         const u32 g2 = ctx->tx_group_log2 >= 0 ? (u32)ctx->tx_group_log2 : tx_group_log2_for(mean_payload, iface->mode == UNET_MODE_L2);
         const u32 group = 1u << g2;
         const u32 wpb = group > ctx->tx_wave_block / kWave ? group : ctx->tx_wave_block / kWave;  // waves per workgroup
@@ -1324,6 +1324,12 @@ int unet_tx_build_opts_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload
         }
     }
     if ((rc = check_tiles(n, b.tile_n))) return rc;
+    // Output staging in LDS (k_tx_build) costs the launch 40 KiB of LDS per workgroup, which only pays if tiles qualify:
+    // batches of short packets (up to 320 bytes of mean payload), and longer ones when no payload can be long -- a fixed
+    // stride of at most 1008 bytes, or lengths the host has seen.  A packed batch of mixed sizes goes without.
+    const u64 longest_group_payload = 16u * (kWave - (iface->mode == UNET_MODE_L2 ? 3u : 2u));
+    const bool stage = ctx->tx_stage && (tile >= 32 || (payload_stride16 != 0 && (u64)payload_stride16 * 16u <= longest_group_payload + 15u) ||
+                                         (ctx->len_known && ctx->max_len_known <= longest_group_payload));
     if (iface->mode == UNET_MODE_L2) {
         if (tile <= 8) UNET_TX_LAUNCH(MODE_L2, 8);
         else if (tile == 16) UNET_TX_LAUNCH(MODE_L2, 16);
