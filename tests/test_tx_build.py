@@ -334,7 +334,8 @@ def _check_against_oracle(got, got_len, got_status, exp, exp_len, exp_status, oo
 def test_tx_build_tiles_of_short_packets_staged_in_lds(offload, mode):
     """Tiles whose packets lie back to back in the output arena are assembled in LDS and leave as whole rows: uniform
     lengths on both sides of every limit (one lane up to 48 or 80 bytes, groups of 4 / 8 / 16 lanes, what the staging
-    area of 64-, 32- and 16-packet tiles holds), output ranges that start on every chunk of a 128-byte line, batches
+    area of 64-, 32-, 16- and 8-packet tiles holds: a tile of short packets that is longer stages its first packets and
+    stores the rest directly), output ranges that start on every chunk of a 128-byte line, batches
     that end inside a tile -- and the tiles that must not take that route: a refused packet, a gap or a step back in
     the output offsets, a long payload among the short ones."""
     rng = np.random.default_rng(101 + mode)

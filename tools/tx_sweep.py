@@ -2,7 +2,9 @@
 """Bandwidth of k_tx_build as a function of payload size (UDP, L3 and L2 output), HIP-event timing."""
 import json
 import os
+import statistics
 import sys
+import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -41,15 +43,22 @@ for mode in (0, 1):
         def run():
             ctx.tx_build_dev(buf.data_ptr(), n * slots * 16, None, slots, d_plen.data_ptr(), d_desc.data_ptr(), n, ifc, d_out.data_ptr(),
                              n * oslots * 16, d_ooff.data_ptr(), d_olen.data_ptr(), d_st.data_ptr(), st.cuda_stream, flags=flags)
-        for _ in range(3):
+        # warm up for at least 40 ms (the descriptor set-up above leaves the GPU idle long enough for its clocks to drop:
+        # three launches measured 5-10 % low at some sizes), then the median of seven groups of four launches
+        t_warm = time.perf_counter()
+        while time.perf_counter() - t_warm < 0.04:
             run()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 10
+            torch.cuda.synchronize()
+        groups = []
+        for _ in range(7):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            groups.append(e0.elapsed_time(e1) / 4)
+        ms = statistics.median(groups)
         assert int(d_st.max().item()) == 0 and int(d_olen.min().item()) == flen
         print(json.dumps({"mode": "L2" if mode else "L3", "layout": "lines+fill" if flags else "packed", "payload": L, "packet": flen, "packets": n,
                           "GBps": round(n * (L + flen + 41) / ms / 1e6, 1), "Gpkt_s": round(n / ms / 1e6, 3)}), flush=True)

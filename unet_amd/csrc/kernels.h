@@ -1295,23 +1295,28 @@ struct TxRows {
 __device__ __forceinline__ void tx_store_small(u32x4 v, u32x4* p) { *p = v; }
 
 // Where the single-lane and lane-group paths put a packet's output chunk m: into the output arena, or -- when the tile's
-// packets lie back to back there and fit the wave's staging area -- into LDS at the chunk's place in the tile's output
-// range, which then leaves as whole 1 KiB rows (tx_flush_staged).  `staged` is wave-uniform.
+// packets lie back to back there -- into LDS at the chunk's place in the tile's output range, which then leaves as whole
+// 1 KiB rows (tx_flush_staged).  A tile that is longer than the wave's staging area stages as many of its first
+// packets as fit and stores the rest directly.  `staged` is wave-uniform.
 struct TxSink {
     uint8_t* out_arena;
     u32x4* area;   // LDS
     u32 base;      // first chunk of the staged range (on a 128-byte line)
     u32 limit;     // chunks the area holds
+    u32 span;      // chunks of the staged range: the tile's output, or as many of its first packets as the area holds
     bool staged;
-    __device__ __forceinline__ void store(u32 oslot, u32 m, u32x4 v) const {
-        if (staged) UNET_LDS_STORE(area, oslot - base + m, limit, v);
+    // is a packet of `nout` output chunks at `oslot` inside the staged range?
+    __device__ __forceinline__ bool holds(u32 oslot, u32 nout) const { return staged && oslot - base + nout <= span; }
+    __device__ __forceinline__ void store(u32 oslot, u32 m, u32x4 v, bool in_stage) const {
+        if (in_stage) UNET_LDS_STORE(area, oslot - base + m, limit, v);
         else tx_store_small(v, reinterpret_cast<u32x4*>(out_arena + (u64)oslot * 16u) + m);
     }
 };
 
 // Chunks [lead, span) of the staged range, row by row: whole lines with streaming stores, the range's first and last
 // line -- shared with the neighbouring tiles when they start or end inside them -- with the default policy.
-__device__ __forceinline__ void tx_flush_staged(const TxSink& k, u32 lane, u32 lead, u32 span) {
+__device__ __forceinline__ void tx_flush_staged(const TxSink& k, u32 lane, u32 lead) {
+    const u32 span = k.span;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     u32x4* q = reinterpret_cast<u32x4*>(k.out_arena + (u64)k.base * 16u);
@@ -1517,9 +1522,10 @@ __device__ __forceinline__ void tx_build_small(const Batch& pay, u32 my_len, u32
     const u32 ck = bswap16((~fold16(l4_partial_be + pay_be)) & 0xffffu) << 16;
     v[SH - 1u].w |= udp ? ck : 0u;
     v[SH - 1u].z |= udp ? 0u : ck;
+    const bool in_stage = sink.holds(my_oslot, nout);
 #pragma unroll
     for (u32 c = 0; c < SH + N; ++c)
-        if (c < nout) sink.store(my_oslot, c, splice<R>(v[c], v[c + 1u]));
+        if (c < nout) sink.store(my_oslot, c, splice<R>(v[c], v[c + 1u]), in_stage);
 }
 
 // Packets of at most 4*W chunks (payloads of up to 4*W - SH chunks), 64/W at a time, one per group of W
@@ -1605,13 +1611,14 @@ __device__ __forceinline__ void consume_tx_step(const TxRowStep& g, u32 lane, co
     x0.w |= ck_lane && g.udp ? ck : 0u;
     x0.z |= ck_lane && !g.udp ? ck : 0u;
     const bool last_of_group = sub == W - 1u;
+    const bool in_stage = sink.holds(g.oslot, nout);
 #define UNET_TXM_EMIT(X, NX, NY, I)                                                      \
     {                                                                                    \
         u32x4 h_ = {0, 0, 0, 0};                                                         \
         h_.x = from_next_in_group<W>(X.x, NX, last_of_group);                            \
         if (R > 4) h_.y = from_next_in_group<W>(X.y, NY, last_of_group);                 \
         const u32 m_ = W * (I) + sub;                                                    \
-        if (m_ < nout) sink.store(g.oslot, m_, splice<R>(X, h_));                        \
+        if (m_ < nout) sink.store(g.oslot, m_, splice<R>(X, h_), in_stage);              \
     }
     UNET_TXM_EMIT(x0, x1.x, x1.y, 0u)
     UNET_TXM_EMIT(x1, x2.x, x2.y, 1u)
@@ -1791,22 +1798,29 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx
     const bool any = todo != 0ull;
     // Output staging: every packet of the tile is built by one lane or a lane group, and their output chunks lie back to
     // back in the arena (any packed layout) within the staging area's size.
-    TxSink sink{out_arena, lds_stage + (threadIdx.x >> 6) * kStage, 0u, kStage, false};
-    u32 stage_lead = 0, stage_span = 0;
+    TxSink sink{out_arena, lds_stage + (threadIdx.x >> 6) * kStage, 0u, kStage, 0u, false};
+    u32 stage_lead = 0;
     const bool short_if_staged = UNET_TX_SMALL_PATH && my_go && t.my_len <= 16u * kTxSmallStaged;
+    const u32 my_cover = ((short_if_staged ? frame_len : store_len) + 15u) >> 4;  // chunks this packet's stores cover
     if (kStage != 0u && !any && (flags & kTxNoStage) == 0u) {
-        const u32 my_cover = ((short_if_staged ? frame_len : store_len) + 15u) >> 4;  // chunks this packet's stores cover
         const bool in = t.lane < t.cnt, is_last = t.lane + 1u >= t.cnt;
         const u32 next_oslot = from_next_lane(my_oslot, 0xffffffffu);
         if (__ballot(!in || (my_go && (is_last || my_oslot + my_cover == next_oslot))) == ~0ull) {
-            const u32 lo = rdlane(my_oslot, 0u), end = rdlane(my_oslot + my_cover, t.cnt - 1u);
+            const u32 lo = rdlane(my_oslot, 0u);
             sink.base = lo & ~7u;
             stage_lead = lo & 7u;
-            stage_span = end - sink.base;
-            sink.staged = stage_span <= kStage;
+            // the packets whose end lies inside the area: all of them, or -- tiles of 32 and 64 short packets, where
+            // staging gains most; sixteen 600-byte payloads lose 2 % with fifteen staged -- the tile's first ones, at least
+            // half of it
+            const u64 inside = __ballot(in && my_oslot + my_cover - sink.base <= kStage);
+            if (inside != 0ull) {
+                const u32 last_in = 63u - (u32)__builtin_clzll(inside);
+                sink.span = rdlane(my_oslot + my_cover, last_in) - sink.base;
+                sink.staged = TILE >= 32 ? 2u * (last_in + 1u) >= t.cnt : last_in + 1u == t.cnt;
+            }
         }
     }
-    const bool my_small = sink.staged ? short_if_staged : small3;
+    const bool my_small = sink.holds(my_oslot, my_cover) ? short_if_staged : small3;
     const bool my_mid = fits_groups && !my_small;
     const bool my_g4 = UNET_TX_G4 && my_mid && t.my_len <= 16u * (16u - SH);
     const bool my_g8 = my_mid && !my_g4 && t.my_len <= 16u * (32u - SH);
@@ -1857,7 +1871,7 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx
         tx_build_small<R, SH, kTxSmallChunks>(pay, t.my_len, t.my_slot, frame_len, sink, my_oslot, park + t.lane * SH, my_partial, my_udp,
                                               kTxSmallChunks);
     }
-    if (sink.staged) tx_flush_staged(sink, t.lane, stage_lead, stage_span);
+    if (sink.staged) tx_flush_staged(sink, t.lane, stage_lead);
 
     // ---- three register buffers in rotation, as in tile_sums: the loads of the next two payloads are
     // in flight while one packet is assembled and stored
