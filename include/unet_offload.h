@@ -486,6 +486,15 @@ int unet_stream_read_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint
  * A benchmark takes the better of the two as what a pure read of its buffer attains on that GPU. */
 int unet_stream_read_pieces_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t bytes,
                                 uint32_t* d_sink);
+/* The same pieces with as many resident wavefronts as the CU holds (the call above caps them at three workgroups per
+ * CU, which reads faster on most GPUs of this type and slower on some). */
+int unet_stream_read_pieces_full_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t bytes,
+                                     uint32_t* d_sink);
+/* A third shape: the buffer read as packed records of `record_bytes` each (rounded up to 16), sixteen to a wavefront,
+ * with the loads the record kernels issue -- whole streaming rows and one cached row holding the record's end -- and
+ * only a sum taken.  (A measurement aid: it keeps a table of n equal lengths in the context and may allocate it.) */
+int unet_stream_read_records_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t bytes, uint32_t record_bytes,
+                                 uint32_t* d_sink);
 /* Debug builds only (hipcc -DUNET_DEBUG, e.g. tools/variants.sh debug): every store the kernels make into a
  * wavefront's LDS area is checked against that area's bounds; a store outside is dropped and counted, and this call
  * waits for the device and returns the count (reset != 0: and zeroes it).  A release build returns UNET_E_INVAL.

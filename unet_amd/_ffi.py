@@ -201,6 +201,8 @@ _SIGS = {
     "unet_pcap_write": (C.c_int, [_u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.c_uint32, _u8p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "unet_stream_read_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p]),
     "unet_stream_read_pieces_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p]),
+    "unet_stream_read_pieces_full_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, _u32p]),
+    "unet_stream_read_records_dev": (C.c_int, [_vp, _vp, _u8p, C.c_uint64, C.c_uint32, _u32p]),
     "unet_stream_copy_dev": (C.c_int, [_vp, _vp, _u8p, _u8p, C.c_uint64]),
     "unet_debug_lds_violations": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.c_int]),
 }
@@ -631,6 +633,12 @@ class Offload:
 
     def stream_read_pieces_dev(self, d_buf, nbytes, d_sink, stream=None):
         _check(self.lib.unet_stream_read_pieces_dev(self.h, stream, d_buf, nbytes, d_sink))
+
+    def stream_read_pieces_full_dev(self, d_buf, nbytes, d_sink, stream=None):
+        _check(self.lib.unet_stream_read_pieces_full_dev(self.h, stream, d_buf, nbytes, d_sink))
+
+    def stream_read_records_dev(self, d_buf, nbytes, record_bytes, d_sink, stream=None):
+        _check(self.lib.unet_stream_read_records_dev(self.h, stream, d_buf, nbytes, record_bytes, d_sink))
 
     def debug_lds_violations(self, reset: bool = False):
         """Out-of-area LDS stores counted by a -DUNET_DEBUG build, or None when the library is a release build."""

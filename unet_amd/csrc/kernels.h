@@ -2142,6 +2142,48 @@ __global__ __launch_bounds__(kBlock) void k_stream_read_pieces(const u32x4* __re
     if (lane == 0u) atomicAdd(&sink[wave & 4095u], acc);
 }
 
+// Third shape: the record kernels' own read loop and nothing else -- fixed-size records of `rec_chunks` chunks, sixteen
+// to a wave, requested by issue_rows and summed by stream_one exactly as k_verify and k_csum do (three register
+// buffers in rotation, streaming rows plus one default-policy row that holds the record's end), with no headers parked,
+// no parse and no result.  (On about half of the boxes every one of these shapes comes out 1-2.5 % below k_verify
+// itself, 6.75-6.88 against 6.95 TB/s on the same buffer -- this one, with less work per byte on the same loads,
+// included; it is fastest with four workgroups to a CU.  The verdict kernel's waves alternate between requesting and
+// arithmetic, which thins the request stream out much as an occupancy cap does.)
+__global__ __launch_bounds__(kBlock, 6) void k_stream_read_records(Batch b, u32* __restrict__ sink) {
+    Tile t;
+    if (!t.init<16>(b)) return;
+    u64 todo = __ballot(t.lane < t.cnt && t.my_ok);
+    u32 acc = 0;
+    Rows2 A, B, C;
+#define UNET_NEXT(R)                                                                 \
+    {                                                                                \
+        const bool has = todo != 0ull;                                               \
+        const u32 j = has ? (u32)__builtin_ctzll(todo) : 0u;                         \
+        todo &= todo - 1ull;                                                         \
+        R = issue_rows(b, t.my_len, t.my_slot, t.lane, j, has);                      \
+    }
+#define UNET_CONSUME(R) acc += stream_one<false, 16u>(R, t.lane, nullptr);
+    if (todo != 0ull) {
+        UNET_NEXT(A)
+        UNET_NEXT(B)
+#pragma nounroll
+        while (true) {
+            UNET_NEXT(C)
+            UNET_CONSUME(A)
+            if (!B.live) break;
+            UNET_NEXT(A)
+            UNET_CONSUME(B)
+            if (!C.live) break;
+            UNET_NEXT(B)
+            UNET_CONSUME(C)
+            if (!A.live) break;
+        }
+    }
+#undef UNET_NEXT
+#undef UNET_CONSUME
+    if (t.lane == 0u) atomicAdd(&sink[(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) & 4095u], acc);
+}
+
 // Read+write yardstick: plain copy with the same access pattern (slab per workgroup, 16 bytes per lane).
 __global__ __launch_bounds__(kBlock) void k_stream_copy(const u32x4* __restrict__ src, u32x4* __restrict__ dst, u64 nchunks) {
     const u64 per = ((nchunks + gridDim.x - 1) / gridDim.x + 63u) & ~63ull;  // slabs start on 1 KiB boundaries

@@ -193,7 +193,9 @@ struct unet_ctx {
     u64 zero_copy_bytes = 4u << 20;            // staging images up to this size may be read in place (UNET_ZERO_COPY_BYTES)
     hipEvent_t pinned_free[2] = {nullptr, nullptr};
     hipEvent_t copied = nullptr;
-    DevBuf d_arena, d_off, d_len, d_out, d_aux, d_tx, d_tx_tab, d_tcp;
+    DevBuf d_arena, d_off, d_len, d_out, d_aux, d_tx, d_tx_tab, d_tcp, d_len_fill;
+    u64 len_fill_n = 0;           // unet_stream_read_records_dev: d_len_fill holds this many copies of len_fill_v
+    u32 len_fill_v = 0;
     CopyPool* pool = nullptr;
     int tile_override = 0;        // UNET_TILE, read once at unet_open
     int tx_tile_override = 0;     // UNET_TX_TILE (1, 2, 4, 8, 16, 32, 64), read once at unet_open
@@ -634,7 +636,7 @@ void unet_close(unet_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->s_comp) (void)hipStreamSynchronize(c->s_comp);
     if (c->s_copy) (void)hipStreamSynchronize(c->s_copy);
-    DevBuf* bufs[] = {&c->d_arena, &c->d_off, &c->d_len, &c->d_out, &c->d_aux, &c->d_tx, &c->d_tx_tab, &c->d_tcp};
+    DevBuf* bufs[] = {&c->d_arena, &c->d_off, &c->d_len, &c->d_out, &c->d_aux, &c->d_tx, &c->d_tx_tab, &c->d_tcp, &c->d_len_fill};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < 2; i++) {
@@ -1795,7 +1797,7 @@ int unet_stream_read_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint
     return UNET_OK;
 }
 
-int unet_stream_read_pieces_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t bytes, uint32_t* d_sink) {
+static int stream_read_pieces(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t bytes, uint32_t* d_sink, u32 pad_lds) {
     if (!ctx || !d_buf || !d_sink) return fail(UNET_E_INVAL, "null argument");
     if (((uintptr_t)d_buf & 15u) != 0) return fail(UNET_E_INVAL, "buffer must be 16-byte aligned");
     const u64 nchunks = bytes / 16, per_block = (u64)kPieceChunks * (kBlock / kWave);
@@ -1803,9 +1805,44 @@ int unet_stream_read_pieces_dev(unet_ctx* ctx, void* stream, const uint8_t* d_bu
     if (grid == 0) return UNET_OK;
     if (grid * kBlock >= (1ull << 32)) return fail(UNET_E_RANGE, "buffer of %llu bytes is too large for one launch", (unsigned long long)bytes);
     HIP_TRY(hipSetDevice(ctx->device));
-    // unused LDS so that at most three workgroups share a CU's 160 KiB: fewer resident waves read faster (see the kernel)
-    constexpr u32 kPadLds = (160u << 10) / 3u - 1024u;
-    hipLaunchKernelGGL(k_stream_read_pieces, dim3((u32)grid), dim3(kBlock), kPadLds, pick(ctx, stream), (const u32x4*)d_buf, nchunks, d_sink);
+    hipLaunchKernelGGL(k_stream_read_pieces, dim3((u32)grid), dim3(kBlock), pad_lds, pick(ctx, stream), (const u32x4*)d_buf, nchunks, d_sink);
+    HIP_TRY(hipGetLastError());
+    return UNET_OK;
+}
+
+int unet_stream_read_pieces_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t bytes, uint32_t* d_sink) {
+    // unused LDS so that at most three workgroups share a CU's 160 KiB: fewer resident waves read faster on most boxes (see the kernel)
+    return stream_read_pieces(ctx, stream, d_buf, bytes, d_sink, (160u << 10) / 3u - 1024u);
+}
+
+int unet_stream_read_pieces_full_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t bytes, uint32_t* d_sink) {
+    return stream_read_pieces(ctx, stream, d_buf, bytes, d_sink, 0u);
+}
+
+int unet_stream_read_records_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t bytes, uint32_t record_bytes, uint32_t* d_sink) {
+    if (!ctx || !d_buf || !d_sink) return fail(UNET_E_INVAL, "null argument");
+    if (((uintptr_t)d_buf & 15u) != 0) return fail(UNET_E_INVAL, "buffer must be 16-byte aligned");
+    if (record_bytes == 0 || record_bytes > kMaxLen) return fail(UNET_E_RANGE, "record size %u: 1..65535 bytes", record_bytes);
+    const u32 stride16 = (record_bytes + 15u) / 16u;
+    const u64 nrec = bytes / 16 / stride16;
+    if (nrec == 0) return UNET_OK;
+    if (nrec > 0xffffffffull) return fail(UNET_E_RANGE, "buffer of %llu bytes holds more than 2^32 records of %u bytes", (unsigned long long)bytes, record_bytes);
+    int rc = check_tiles((u32)nrec, 16);
+    if (rc) return rc;
+    // the records' lengths: one table of equal entries, kept in the context (this call is a measurement aid: it may allocate)
+    if (ctx->d_len_fill.cap < (size_t)nrec * 4) ctx->len_fill_n = 0;
+    if ((rc = ensure(ctx, ctx->d_len_fill, (size_t)nrec * 4))) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = pick(ctx, stream);
+    if (ctx->len_fill_n < nrec || ctx->len_fill_v != stride16 * 16u) {  // (filled once per record size, not per call)
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ctx->d_len_fill.p, (int)(stride16 * 16u), (size_t)nrec, s));
+        ctx->len_fill_n = nrec;
+        ctx->len_fill_v = stride16 * 16u;
+    }
+    Batch b{d_buf, bytes, nullptr, stride16, (const u32*)ctx->d_len_fill.p, (u32)nrec};
+    // unused LDS so that four workgroups share a CU (measured best of 2..8: 6.87 TB/s against 6.75 with eight, 6.55 with three)
+    const u32 pad = (160u << 10) / 4u - 1024u;
+    hipLaunchKernelGGL(k_stream_read_records, dim3(tiles_grid((u32)nrec, 16)), dim3(kBlock), pad, s, b, d_sink);
     HIP_TRY(hipGetLastError());
     return UNET_OK;
 }
