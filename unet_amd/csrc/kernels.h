@@ -76,6 +76,11 @@ __device__ unsigned int g_lds_out_of_area = 0;
 #ifndef UNET_TX_MID_PATH
 #define UNET_TX_MID_PATH 1    // k_tx_build: lane groups for packets of up to 64 chunks
 #endif
+#ifndef UNET_TX_MID_DEPTH
+#define UNET_TX_MID_DEPTH 1   // k_tx_build, lane groups: steps in flight.  2 (the next step's loads go out before the current one is built) costs
+                              // 20 registers and with them the fifth wave per SIMD: the IMIX payload mix 4.70 -> 4.79 TB/s with 1, uniform sizes
+                              // within +-1.5 % (profiles/r3/tx_mid_depth_ab.log)
+#endif
 #ifndef UNET_TX_STAGE
 #define UNET_TX_STAGE 1       // k_tx_build: tiles of short packets that lie back to back in the output arena are assembled in LDS and stored as whole rows
 #endif
@@ -1532,7 +1537,7 @@ __device__ __forceinline__ void tx_build_small(const Batch& pay, u32 my_len, u32
 // (4, 8 or 16) neighbouring lanes: lane `sub` of a group holds virtual chunks sub, sub+W, sub+2W, sub+3W of
 // its group's packet (header chunks from LDS, payload chunks loaded SH chunks further left), the payload's
 // sum is reduced inside the group, and a chunk's neighbour comes from the next lane of the group -- or,
-// for the group's last lane, from its first lane's chunk of the next step.  Two steps are in flight.
+// for the group's last lane, from its first lane's chunk of the next step.  One step is in flight (UNET_TX_MID_DEPTH).
 // `list` holds the tile's packets of this class, in lane order.
 struct TxRowStep {
     u32x4 v0, v1, v2, v3;
@@ -1639,6 +1644,13 @@ __device__ __forceinline__ void tx_rows_path(const Batch& pay, const Tile& t, bo
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     u32 next = 0;
+#if UNET_TX_MID_DEPTH == 1
+#pragma nounroll
+    for (; next < count; next += kPerStep) {
+        const TxRowStep g = issue_tx_step<W, SH>(pay, t, my_flen, my_oslot, my_partial, my_udp, list, next, count);
+        consume_tx_step<W, R, SH>(g, t.lane, sink, park);
+    }
+#else
     TxRowStep g0 = issue_tx_step<W, SH>(pay, t, my_flen, my_oslot, my_partial, my_udp, list, next, count), g1;
     next += kPerStep;
 #pragma nounroll
@@ -1652,6 +1664,7 @@ __device__ __forceinline__ void tx_rows_path(const Batch& pay, const Tile& t, bo
         if (next >= count) break;
         next += kPerStep;
     }
+#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the list is reused by the next class
     __builtin_amdgcn_wave_barrier();
 }
