@@ -76,6 +76,10 @@ __device__ unsigned int g_lds_out_of_area = 0;
 #ifndef UNET_TX_MID_PATH
 #define UNET_TX_MID_PATH 1    // k_tx_build: lane groups for packets of up to 64 chunks
 #endif
+#ifndef UNET_TX_TILE_BURST
+#define UNET_TX_TILE_BURST 4   // k_tx_build: rows of a long payload past its first two requested together (4; 2 saves three registers and
+                               // costs the IMIX payload mix 1 %: 4.74 against 4.79 TB/s)
+#endif
 #ifndef UNET_TX_MID_DEPTH
 #define UNET_TX_MID_DEPTH 1   // k_tx_build, lane groups: steps in flight.  2 (the next step's loads go out before the current one is built) costs
                               // 20 registers and with them the fifth wave per SIMD: the IMIX payload mix 4.70 -> 4.79 TB/s with 1, uniform sizes
@@ -1390,7 +1394,7 @@ struct TxPkt {
 // row spliced with the first dwords of the next and stored; the last step asks only for the rows that exist.  The loads
 // are clamped to the payload's last chunk and zeroed past its end.  more_behind: the packet goes on past k_end (in
 // another wave's hands).  Returns acc + the lanes' sums over these chunks.
-template <int R, u32 SH>
+template <int R, u32 SH, int BURST = 4>
 __device__ __forceinline__ u32 tx_rows(const TxPkt& t, u32 lane, u32 k, u32 k_end, u32 acc, bool more_behind) {
 #define UNET_TX_ROW(X, K) X = t.chunk((K) + lane)
 #define UNET_TX_EMIT(X, NEXT, K)                                                                  \
@@ -1400,6 +1404,26 @@ __device__ __forceinline__ u32 tx_rows(const TxPkt& t, u32 lane, u32 k, u32 k_en
         h_.x = from_next_lane(X.x, rdlane(NEXT.x, 0));                                            \
         if (R > 4) h_.y = from_next_lane(X.y, rdlane(NEXT.y, 0));                                 \
         if ((K) + lane + SH < t.nout) tx_store(splice<R>(X, h_), t.pout + (K) + lane + SH);       \
+    }
+    if (BURST == 2) {
+        // the tile kernel's form: two rows at a time (eight registers fewer, which is its sixth wave per SIMD)
+        u32x4 ra, rb;
+#pragma nounroll
+        for (; k + 2u * kWave <= k_end; k += 2u * kWave) {
+            UNET_TX_ROW(ra, k);
+            UNET_TX_ROW(rb, k + kWave);
+            u32x4 pk = {0, 0, 0, 0};
+            if (more_behind || k + 2u * kWave < k_end) pk = t.chunk(k + 2u * kWave);
+            UNET_TX_EMIT(ra, rb, k)
+            UNET_TX_EMIT(rb, pk, k + kWave)
+        }
+        if (k < k_end) {
+            u32x4 pk = {0, 0, 0, 0};
+            if (more_behind) pk = t.chunk(k + kWave);
+            UNET_TX_ROW(ra, k);
+            UNET_TX_EMIT(ra, pk, k)
+        }
+        return acc;
     }
     u32x4 ra, rb, rc, rd;
 #pragma nounroll
@@ -1466,7 +1490,7 @@ constexpr u32 tx_rows01_chunks(u32 SH) { return 2u * kWave - SH; }  // payload c
 // payload chunk k.  Output chunk m = bytes R..15 of virtual chunk m followed by bytes 0..R-1 of virtual
 // chunk m + 1, which sits in the next lane's registers.  The part of a payload past rows 0/1 is streamed
 // through first (tx_rows); rows 0/1 are stored last (tx_finish).
-template <int R, u32 SH, class Hdr>
+template <int R, u32 SH, int BURST, class Hdr>
 __device__ __forceinline__ void tx_build_one(const TxRows& cur, u32 lane, u32 frame_len, u32x4* __restrict__ pout,
                                              const Hdr& hdr, u32 l4_partial_be, bool udp) {
     const TxPkt t(cur.p, cur.flen, cur.nch, frame_len, pout);
@@ -1481,7 +1505,7 @@ __device__ __forceinline__ void tx_build_one(const TxRows& cur, u32 lane, u32 fr
         const u32x4 pk = t.chunk(kRows);
         fx = rdlane(pk.x, 0);
         fy = rdlane(pk.y, 0);
-        acc = tx_rows<R, SH>(t, lane, kRows, kend, acc, false);
+        acc = tx_rows<R, SH, BURST>(t, lane, kRows, kend, acc, false);
     }
     tx_finish<R, SH>(t, lane, a, c, fx, fy, wave_sum(acc), hdr, l4_partial_be, udp);
 }
@@ -1889,7 +1913,7 @@ __global__ __launch_bounds__(kBlock, UNET_TX_OCC * (256 / UNET_BLOCK)) void k_tx
     // ---- three register buffers in rotation, as in tile_sums: the loads of the next two payloads are
     // in flight while one packet is assembled and stored
 #define UNET_CONSUME(X)                                                              \
-    tx_build_one<R, SH>(X, t.lane, rdlane(store_len, X.j),                           \
+    tx_build_one<R, SH, UNET_TX_TILE_BURST>(X, t.lane, rdlane(store_len, X.j),                           \
                         reinterpret_cast<u32x4*>(out_arena + (u64)rdlane(my_oslot, X.j) * 16u), TxHdrLds{park + X.j * SH}, \
                         rdlane(my_partial, X.j), rdlane((u32)my_udp, X.j) != 0u);
     if (any) {
