@@ -133,6 +133,12 @@ int unet_sync(unet_ctx* ctx);
  * wrong for an arena with gaps.  A caller that knows better says so here (0 = back to the estimate).  Only
  * speed depends on it, never results. */
 int unet_hint_mean_len(unet_ctx* ctx, uint32_t mean_len);
+/* The same for the longest record (or, for unet_tx_build_dev, payload) of the batches to come, 0 = not known.  With it
+ * a batch of records of at most 64 bytes gets 64-record tiles although only its mean could be estimated, and
+ * unet_tx_build_dev reserves its LDS staging area for batches of mid-size payloads (up to 1008 bytes, 994 for Ethernet
+ * output) that come with an offset table -- without it only for short ones and for fixed strides.  Only speed depends
+ * on it, never results: a record longer than the hint is still handled correctly. */
+int unet_hint_max_len(unet_ctx* ctx, uint32_t max_len);
 /* The number of records one wavefront is given for a batch whose mean record length is `mean_len` bytes and whose
  * longest record is `max_len` bytes (0 = not known, as for the *_dev entry points): 64, 48, 40, 32, 16, 8, 4, 2 or
  * 1.  A pure function of its arguments that touches no GPU -- for logs, for sizing experiments with UNET_TILE, and

@@ -389,6 +389,30 @@ def test_tx_build_tiles_of_short_packets_staged_in_lds(offload, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [unet_amd.MODE_L3, unet_amd.MODE_L2])
+def test_tx_build_max_length_hint_changes_the_route_not_the_bytes(offload, mode):
+    """unet_hint_max_len: packed batches of mid-size payloads (an offset table, no stride) are staged in LDS only on the
+    caller's word that none is long; a payload that breaks the word is built correctly all the same."""
+    rng = np.random.default_rng(211 + mode)
+    ifc = unet_amd.Iface("192.0.2.2", "255.255.255.0", mac=bytes.fromhex("02aabbccddee"), mode=mode)
+    for lens in ([400] * 300, [548] * 211, [int(x) for x in rng.integers(330, 600, size=257)],
+                 [500] * 100 + [3000] + [500] * 100):
+        desc, payloads = make_batch(rng, lens, ifc)
+        arena, off16, plen = unet_amd.pack_arena(payloads, pad_byte=0x77)
+        ooff, obytes = tx_out_layout(plen, mode)
+        ooff = ooff + np.uint32(5)
+        obytes += 80
+        exp, exp_len, exp_status = O.tx_build_batch(arena, off16, plen, desc, ifc, ooff, obytes)
+        try:
+            for hint in (0, 900, 64):
+                offload.hint_max_len(hint)
+                got, got_len, got_status = _gpu_build(offload, arena, off16, plen, desc, ifc, ooff, obytes)
+                _check_against_oracle(got, got_len, got_status, exp, exp_len, exp_status, ooff, obytes)
+        finally:
+            offload.hint_max_len(0)
+
+
+@pytest.mark.gpu
 def test_tx_build_fixed_stride_and_status(offload):
     rng = np.random.default_rng(3)
     ifc = unet_amd.Iface()

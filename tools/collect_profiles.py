@@ -56,7 +56,7 @@ for w, k in kern.items():
         j["roofline"]["traffic"] = r["traffic_bytes"]
         j["roofline"]["traffic_source"] = t[w]["source"] + "; joined to this line by tools/collect_profiles.py, same run of tools/profile_all.sh, same kernel digest"
         json.dump(j, open(f"{D}/bench_{w}_1gpu.json", "w"))
-    rows = list(csv.DictReader(open(f"{P}/{w}_stats/s_kernel_stats.csv")))
+    rows = [r for r in csv.DictReader(open(f"{P}/{w}_stats/s_kernel_stats.csv")) if k in r["Name"]] or list(csv.DictReader(open(f"{P}/{w}_stats/s_kernel_stats.csv")))
     ro = j["roofline"]
     print(w, rows[0]["Name"][:36], rows[0]["Calls"], round(float(rows[0]["AverageNs"]) / 1e3, 1), "us | bench ms", round(ro["kernel_ms"], 4), "GB/s",
           round(ro["achieved"]), "frac", round(ro["frac"], 3), "value", round(j["value"], 3), "traffic/alg", round(r["traffic_bytes"] / alg, 4),

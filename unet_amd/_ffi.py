@@ -162,6 +162,7 @@ _SIGS = {
     "unet_counters_sum": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, _u64p, C.c_int]),
     "unet_verify_static": (C.c_int, [_vp, _u8p, C.c_uint64, _u32p, C.c_uint32, _u32p, C.c_uint32, C.POINTER(_IfaceC), _vp]),
     "unet_hint_mean_len": (C.c_int, [_vp, C.c_uint32]),
+    "unet_hint_max_len": (C.c_int, [_vp, C.c_uint32]),
     "unet_records_per_wave": (C.c_int, [C.c_uint32, C.c_uint32]),
     "unet_tx_packets_per_wave": (C.c_int, [C.c_uint32]),
     "unet_tx_waves_per_packet": (C.c_int, [C.c_uint32, C.c_int]),
@@ -518,6 +519,9 @@ class Offload:
 
     def hint_mean_len(self, mean_len: int):
         _check(self.lib.unet_hint_mean_len(self.h, int(mean_len)))
+
+    def hint_max_len(self, max_len: int):
+        _check(self.lib.unet_hint_max_len(self.h, int(max_len)))
 
     def verify_frames(self, frames: Sequence[bytes], iface: Iface) -> np.ndarray:
         arena, off16, lens = pack_arena(frames)

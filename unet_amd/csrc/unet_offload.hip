@@ -208,6 +208,7 @@ struct unet_ctx {
     bool hdr_plain = false;       // UNET_HDR_PLAIN, read once at unet_open
     u32 lds_pad = 0;              // UNET_LDS_PAD: bytes of unused LDS added to every workgroup of the record kernels (experiments: fewer resident workgroups)
     u32 mean_len_hint = 0;        // unet_hint_mean_len
+    u32 max_len_hint = 0;         // unet_hint_max_len
     bool len_known = false;       // set by the host-pointer entry points around their *_dev call
     u32 mean_len_known = 0, max_len_known = 0;
     uint8_t* scratch_dev = nullptr;  // this device's copy of the static scratch array
@@ -329,9 +330,9 @@ inline int pick_tile(const unet_ctx* c, u64 arena_bytes, u32 stride16, u32 n) {
     if (c->tile_once) return c->tile_once;  // set around one launch by a host-pointer entry point
     if (c->tile_override) return c->tile_override;
     if (c->len_known) return tile_for(c->mean_len_known, true, c->max_len_known);
-    if (c->mean_len_hint) return tile_for(c->mean_len_hint, false, 0);
+    if (c->mean_len_hint) return tile_for(c->mean_len_hint, c->max_len_hint != 0, c->max_len_hint);
     if (stride16) return tile_for((u64)stride16 * 16u, true, (u64)stride16 * 16u);
-    return tile_for(arena_bytes / n, false, 0);
+    return tile_for(arena_bytes / n, c->max_len_hint != 0, c->max_len_hint);
 }
 
 // The mean record length as far as it is known (same sources as pick_tile).
@@ -536,6 +537,12 @@ const char* unet_last_error(void) { return g_err; }
 int unet_hint_mean_len(unet_ctx* c, uint32_t mean_len) {
     if (!c) return fail(UNET_E_INVAL, "null context");
     c->mean_len_hint = mean_len;
+    return UNET_OK;
+}
+
+int unet_hint_max_len(unet_ctx* c, uint32_t max_len) {
+    if (!c) return fail(UNET_E_INVAL, "null context");
+    c->max_len_hint = max_len;
     return UNET_OK;
 }
 
@@ -1328,10 +1335,12 @@ int unet_tx_build_opts_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload
     if ((rc = check_tiles(n, b.tile_n))) return rc;
     // Output staging in LDS (k_tx_build) costs the launch 40 KiB of LDS per workgroup, which only pays if tiles qualify:
     // batches of short packets (up to 320 bytes of mean payload), and longer ones when no payload can be long -- a fixed
-    // stride of at most 1008 bytes, or lengths the host has seen.  A packed batch of mixed sizes goes without.
+    // stride of at most 1008 bytes, lengths the host has seen, or the caller's word (unet_hint_max_len).  A packed batch of
+    // mixed sizes goes without.
     const u64 longest_group_payload = 16u * (kWave - (iface->mode == UNET_MODE_L2 ? 3u : 2u));
     const bool stage = ctx->tx_stage && (tile >= 32 || (payload_stride16 != 0 && (u64)payload_stride16 * 16u <= longest_group_payload + 15u) ||
-                                         (ctx->len_known && ctx->max_len_known <= longest_group_payload));
+                                         (ctx->len_known && ctx->max_len_known <= longest_group_payload) ||
+                                         (ctx->max_len_hint != 0 && ctx->max_len_hint <= longest_group_payload));
     if (iface->mode == UNET_MODE_L2) {
         if (tile <= 8) UNET_TX_LAUNCH(MODE_L2, 8);
         else if (tile == 16) UNET_TX_LAUNCH(MODE_L2, 16);
