@@ -121,7 +121,9 @@ typedef struct unet_ctx unet_ctx;
  * place across the host link and write its results into pinned memory: one launch and one wait per call, no copy
  * command.  Larger batches are copied to device memory first.  Environment, read once here: UNET_ZERO_COPY_BYTES
  * (that limit; 0 = always copy), UNET_COPY_THREADS (host threads filling the staging buffers, default 4), and for
- * experiments UNET_TILE / UNET_TX_TILE (records / packets per wave, overriding the library's choice by record size). */
+ * experiments UNET_TILE / UNET_TX_TILE (records / packets per wave, overriding the library's choice by record size),
+ * UNET_TX_WAVE (0: long payloads by tiles too; 2: every batch one packet per wavefront), UNET_TXW_GROUP (wavefronts per
+ * packet), UNET_TXW_BLOCK, UNET_TXW_POLICY and UNET_TX_STAGE (0: no LDS staging of short packets' output). */
 int unet_open(int device_id, unet_ctx** out_ctx);
 void unet_close(unet_ctx* ctx);
 const char* unet_last_error(void);

@@ -161,7 +161,8 @@ def offload(request):
             if v is not None:
                 os.environ[k] = v
     yield ctx
-    ctx.close()
+    from conftest import close_checked
+    close_checked(ctx)
 
 
 def _gpu_build(offload, arena, off16, plen, desc, ifc, ooff, obytes, fill=0xAB, stride16=0, flags=0):
