@@ -2,7 +2,10 @@
 static and asynchronous forms), unet_ipv4_validate, unet_csum_batch, unet_generate and unet_tx_build, every result against the CPU oracle.  Not collected by pytest (it runs for as
 long as it is told to); tests/test_fuzz_short.py runs a few rounds of it.  dev_round sends a batch through the device-pointer entry
 points, where the library chooses records per wave from the arena size, the stride or a caller's hint instead of from the lengths;
-tx_dev_round does the same for unet_tx_build_dev, into packed and into line-aligned output layouts.
+tx_dev_round does the same for unet_tx_build_dev, into packed and into line-aligned output layouts, with and without
+UNET_TX_FILL_LINES and a (true or wrong) unet_hint_max_len.  The transmit rounds go through a rotation of contexts opened
+with the library's kernel knobs set (tile kernel only, one packet per wave or per group of waves, fixed packets per wave),
+so that every route builds every kind of batch, not only the ones the library would choose it for.
 
 usage: python tests/fuzz_parity.py [seconds] [first seed]"""
 import os
@@ -31,6 +34,11 @@ LENGTH_CLASSES = [
     lambda r, n: np.where(r.random(n) < 0.1, r.choice([3000, 9000, 30000, 65535], size=n), r.integers(20, 120, size=n)),
     lambda r, n: np.where(np.arange(n) % int(r.integers(17, 70)) == 0, int(r.choice([20000, 40000, 65535])), r.integers(1, 113, size=n)),
     lambda r, n: r.choice([1100, 1300, 1536, 1537, 2048, 2049, 4096, 8192, 8193, 16384, 49151, 49152], size=n),
+    # around what a lane, a lane group and a wave's LDS staging area take on the transmit side
+    lambda r, n: r.choice([18, 20, 36, 52, 53, 84, 85, 100, 104, 105, 244, 320, 321, 548], size=n),
+    lambda r, n: r.integers(int(r.choice([900, 960, 976])), 1010, size=n),
+    lambda r, n: np.where(r.random(n) < 0.05, r.integers(981, 1100, size=n), r.integers(0, 200, size=n)),
+    lambda r, n: r.choice([36, 548, 1472, 4068, 8972], p=[.56, .32, .08, .02, .02], size=n),
 ]
 
 
@@ -204,7 +212,7 @@ def tx_dev_round(ctx, seed):
     """unet_tx_build_dev on payloads already in device memory, packets packed or on 128-byte lines, with no length hint, a
     true one or a wrong one; every packet byte against the oracle and every byte between packets untouched."""
     import torch
-    from unet_amd._ffi import TX_DESC_DTYPE, tx_out_layout
+    from unet_amd._ffi import TX_DESC_DTYPE, TX_FILL_LINES, tx_out_layout
     rng = np.random.default_rng(seed)
     mode = unet_amd.MODE_L2 if rng.random() < 0.4 else unet_amd.MODE_L3
     ifc = unet_amd.Iface("192.0.2.2", "255.255.255.0", mac=bytes.fromhex("02aabbccddee"), mode=mode)
@@ -221,10 +229,12 @@ def tx_dev_round(ctx, seed):
     desc["ip_id"] = rng.integers(0, 65536, size=n)
     desc["proto"] = np.where(rng.random(n) < 0.3, 1, 17)
     desc["dst_mac"] = rng.integers(0, 256, size=(n, 6), dtype=np.uint8)
-    align16 = int(rng.choice([1, 1, 8, 2]))
+    align16 = int(rng.choice([1, 1, 8, 8, 2]))
     hint = int(rng.choice([0, 0, max(1, int(plen.mean())), 40, 700, 3000, 60000]))
+    max_hint = int(rng.choice([0, 0, max(1, int(plen.max())), 100, 1000]))  # right, absent or wrong: the bytes may not depend on it
+    fill_lines = align16 == 8 and bool(rng.random() < 0.6)  # (only where nothing else lies between a packet's end and its line's)
     ooff, obytes = tx_out_layout(plen, mode, align16)
-    tag = (seed, n, mode, how, int(plen.max()), round(float(plen.mean()), 1), align16, hint)
+    tag = (seed, n, mode, how, int(plen.max()), round(float(plen.mean()), 1), align16, hint, max_hint, fill_lines)
     exp, exp_len, exp_status = O.tx_build_batch(arena, off16, plen, desc, ifc, ooff, obytes, pay_stride16=stride16)
     dev = torch.device("cuda:0")
     d_arena = torch.from_numpy(arena).to(dev)
@@ -237,21 +247,64 @@ def tx_dev_round(ctx, seed):
     d_st = torch.full((n,), 0xEE, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     ctx.hint_mean_len(hint)
+    ctx.hint_max_len(max_hint)
     try:
         ctx.tx_build_dev(d_arena.data_ptr(), arena.nbytes, 0 if d_off is None else d_off.data_ptr(), stride16, d_len.data_ptr(),
-                         d_desc.data_ptr(), n, ifc, d_out.data_ptr(), obytes, d_ooff.data_ptr(), d_olen.data_ptr(), d_st.data_ptr())
+                         d_desc.data_ptr(), n, ifc, d_out.data_ptr(), obytes, d_ooff.data_ptr(), d_olen.data_ptr(), d_st.data_ptr(),
+                         flags=TX_FILL_LINES if fill_lines else 0)
         torch.cuda.synchronize()
     finally:
         ctx.hint_mean_len(0)
+        ctx.hint_max_len(0)
     got, got_len, got_st = d_out.cpu().numpy(), d_olen.cpu().numpy().view(np.uint32), d_st.cpu().numpy()
     assert (got_st == exp_status).all() and (got_len == exp_len).all(), ("tx_dev status", tag)
     keep = np.ones(obytes + 256, dtype=bool)  # bytes no packet's chunks cover
+    may_zero = np.zeros(obytes + 256, dtype=bool)  # with UNET_TX_FILL_LINES: from a packet's last chunk to the end of its 128-byte line
     for o, l in zip(ooff, exp_len):
         a, b = int(o) * 16, int(o) * 16 + int(l)
         assert (got[a:b] == exp[a:b]).all(), ("tx_dev bytes", tag, int(o), int(l))
-        keep[a:a + (int(l) + 15) // 16 * 16] = False
-    assert (got[keep] == 0xAB).all(), ("tx_dev wrote outside its packets", tag)
+        chunk_end = a + (int(l) + 15) // 16 * 16
+        assert (got[b:chunk_end] == 0).all(), ("tx_dev pad of the last chunk", tag, int(o), int(l))
+        keep[a:chunk_end] = False
+        if fill_lines and l:
+            may_zero[chunk_end:min((b + 127) // 128 * 128, obytes)] = True
+    may_zero &= keep  # (a later packet's own bytes are its own)
+    strict = keep & ~may_zero
+    assert (got[strict] == 0xAB).all(), ("tx_dev wrote outside its packets", tag)
+    rest = got[may_zero]
+    assert ((rest == 0) | (rest == 0xAB)).all(), ("tx_dev: something other than zeros behind a packet", tag)
     return tag
+
+
+# The library reads these when a context is opened: which transmit kernel builds a batch, and in what shape.
+TX_CONTEXT_KNOBS = [
+    {},
+    {"UNET_TX_WAVE": "0"},
+    {"UNET_TX_WAVE": "2", "UNET_TXW_GROUP": "1"},
+    {"UNET_TX_WAVE": "2", "UNET_TXW_GROUP": "2"},
+    {"UNET_TX_WAVE": "2", "UNET_TXW_GROUP": "8"},
+    {"UNET_TX_WAVE": "2", "UNET_TXW_GROUP": "16"},
+    {"UNET_TX_WAVE": "2", "UNET_TXW_GROUP": "4", "UNET_TXW_BLOCK": "64", "UNET_TXW_POLICY": "0"},
+    {"UNET_TX_WAVE": "2", "UNET_TXW_GROUP": "1", "UNET_TXW_BLOCK": "128", "UNET_TXW_POLICY": "2"},
+    {"UNET_TX_WAVE": "0", "UNET_TX_TILE": "64"},
+    {"UNET_TX_WAVE": "0", "UNET_TX_TILE": "32"},
+    {"UNET_TX_WAVE": "0", "UNET_TX_TILE": "16"},
+    {"UNET_TX_WAVE": "0", "UNET_TX_TILE": "8"},
+    {"UNET_TX_STAGE": "0"},
+]
+
+
+def open_with(knobs):
+    names = {k for kn in TX_CONTEXT_KNOBS for k in kn}
+    old = {k: os.environ.pop(k, None) for k in names}
+    os.environ.update(knobs)
+    try:
+        return unet_amd.Offload(0)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
 
 
 def main():
@@ -259,17 +312,25 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     t0 = last = time.time()
     rounds = 0
-    with unet_amd.Offload(0) as ctx:
+    ctxs = [open_with(k) for k in TX_CONTEXT_KNOBS]
+    try:
+        ctx = ctxs[0]
         while time.time() - t0 < seconds:
             one_round(ctx, seed + rounds)
-            tx_round(ctx, seed + rounds)
             dev_round(ctx, seed + rounds)
-            tx_dev_round(ctx, seed + rounds)
+            tx_ctx = ctxs[rounds % len(ctxs)]
+            tx_round(tx_ctx, seed + rounds)
+            tx_dev_round(tx_ctx, seed + rounds)
             rounds += 1
             if time.time() - last > 30:
                 last = time.time()
                 print(f"{rounds} rounds, {time.time() - t0:.0f} s", flush=True)
-    print(f"ok: {rounds} rounds from seed {seed}, every result equal to the oracle's")
+    finally:
+        bad = [c.debug_lds_violations() for c in ctxs]
+        for c in ctxs:
+            c.close()
+    assert not any(bad), f"-DUNET_DEBUG library: out-of-area LDS stores counted per context {bad}"
+    print(f"ok: {rounds} rounds from seed {seed}, {len(ctxs)} transmit configurations, every result equal to the oracle's")
 
 
 if __name__ == "__main__":

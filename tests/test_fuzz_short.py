@@ -3,7 +3,7 @@ unet_verify, unet_csum_batch, unet_generate and unet_tx_build, against the CPU o
 import pytest
 
 import unet_amd
-from fuzz_parity import dev_round, one_round, tx_dev_round, tx_round
+from fuzz_parity import TX_CONTEXT_KNOBS, dev_round, one_round, open_with, tx_dev_round, tx_round
 
 pytestmark = pytest.mark.gpu
 
@@ -19,3 +19,17 @@ def test_fuzz_rounds(offload):
     # has no such counter.
     bad = offload.debug_lds_violations()
     assert bad in (None, 0), f"{bad} LDS stores outside their wave's area"
+
+
+@pytest.mark.parametrize("knobs", TX_CONTEXT_KNOBS, ids=lambda k: ",".join(f"{a[5:]}={b}" for a, b in k.items()) or "default")
+def test_fuzz_transmit_rounds_per_kernel_configuration(knobs):
+    """The transmit rounds through a context opened with each set of kernel knobs: every route builds random batches
+    of every length class, layout, hint and flag, not only the batches the library would choose it for."""
+    from conftest import close_checked
+    ctx = open_with(knobs)
+    try:
+        for seed in range(2000, 2012):
+            tx_round(ctx, seed)
+            tx_dev_round(ctx, seed)
+    finally:
+        close_checked(ctx)

@@ -142,6 +142,33 @@ __global__ __launch_bounds__(256) void k_groups_staged(const u32x4* __restrict__
     for (u32 c = lane; c < span; c += 64u) __builtin_nontemporal_store(area[c], q + c);
 }
 
+// A wave's whole input range -- K rows of 64 chunks, `lead` chunks off a 128-byte line -- read as whole rows, all
+// requested at once (streaming loads), placed in LDS `shift` dwords further on (a packet header's worth: the output of
+// a packet builder is its input moved by 28 bytes per packet), and stored from there as whole rows.  The ceiling for
+// a tile kernel that reads its payloads as one stream instead of packet by packet.
+template <u32 K>
+__global__ __launch_bounds__(256) void k_span_staged(const u32x4* __restrict__ src, u32x4* __restrict__ dst, u32 nspans, u32 lead, u32 shift) {
+    extern __shared__ u32x4 lds[];
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const u32 w = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + wv);
+    if (w >= nspans) return;
+    u32* area = reinterpret_cast<u32*>(lds + wv * (K * 64u + 8u));
+    const u32x4* p = src + lead + (u64)w * (K * 64u);
+    u32x4* q = dst + (u64)w * (K * 64u);
+    u32x4 v[K];
+#pragma unroll
+    for (u32 k = 0; k < K; ++k) v[k] = __builtin_nontemporal_load(p + k * 64u + lane);
+#pragma unroll
+    for (u32 k = 0; k < K; ++k) {
+        u32* at = area + shift + (k * 64u + lane) * 4u;
+        at[0] = v[k].x; at[1] = v[k].y; at[2] = v[k].z; at[3] = v[k].w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (u32 k = 0; k < K; ++k) __builtin_nontemporal_store(reinterpret_cast<u32x4*>(area)[k * 64u + lane], q + k * 64u + lane);
+}
+
 template <typename F>
 double timeit(F f, int iters) {
     hipEvent_t a, b;
@@ -168,7 +195,8 @@ __global__ void k_fill_random(u64* buf, u64 nwords) {
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool only_span = argc > 1;  // any argument: only the last section (a tile's input range as rows)
     const u64 bytes = 3ull << 30;
     uint8_t *s, *d;
     CK(hipMalloc(&s, bytes + 4096));
@@ -183,6 +211,7 @@ int main() {
                           {94, 94, 94, 0},   {94, 92, 96, 0},   {96, 92, 96, 0},    {96, 92, 96, 2},   {72, 72, 72, 0},
                           {80, 80, 80, 0},   {112, 112, 112, 0}, {65, 65, 72, 0},   {72, 65, 72, 0}};
     for (const Case& c : cases) {
+        if (only_span) break;
         const u32 stride = c.IS > c.OS ? c.IS : c.OS;
         const u32 n = (u32)((nchunks - 64) / stride) & ~1u;
         const double moved = 2.0 * n * c.P * 16.0;
@@ -207,6 +236,7 @@ int main() {
     struct GCase { u32 W, P; };
     const GCase gcases[] = {{16, 36}, {16, 64}, {16, 52}, {8, 18}, {8, 32}, {4, 10}, {4, 16}, {4, 6}, {4, 3}};
     for (const GCase& c : gcases) {
+        if (only_span) break;
         const u32 n = (u32)((nchunks - 64) / c.P);
         const double moved = 2.0 * n * c.P * 16.0;
         printf("groups of %2u lanes, records of %2u chunks packed:", c.W, c.P);
@@ -237,6 +267,23 @@ int main() {
         }
         printf(" GB/s\n");
         fflush(stdout);
+    }
+    // a tile's whole input range as rows, through LDS, out as rows
+    for (u32 lead : {0u, 3u}) {
+        for (u32 shift : {0u, 7u}) {
+            printf("span of K rows per wave through LDS (input %u chunks off a line, placed %u dwords on):", lead, shift);
+#define SPAN(K_)                                                                                                                   \
+    {                                                                                                                              \
+        const u32 nsp = (u32)((nchunks - 64) / (K_ * 64u));                                                                        \
+        const u32 shm = (K_ * 64u + 8u) * 16u * 4u;                                                                                \
+        const double ms = timeit([&] { hipLaunchKernelGGL((k_span_staged<K_>), dim3((nsp + 3) / 4), dim3(256), shm, 0, (const u32x4*)s, (u32x4*)d, nsp, lead, shift); }, 6); \
+        printf("  K=%u %7.1f", (u32)K_, 2.0 * nsp * K_ * 1024.0 / ms / 1e6);                                                        \
+    }
+            SPAN(1) SPAN(2) SPAN(4) SPAN(6) SPAN(8) SPAN(10)
+#undef SPAN
+            printf(" GB/s\n");
+            fflush(stdout);
+        }
     }
     return 0;
 }
