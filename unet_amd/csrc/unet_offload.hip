@@ -354,17 +354,17 @@ inline int tx_tile_long(u64 mean_payload) {
     return mean_payload < 8000 ? 2 : 1;
 }
 
-// Packets per wave of k_tx_build by mean payload length.  Up to 104 bytes (one lane or four to a packet) 64, up to 320
+// Packets per wave of k_tx_build by mean payload length.  Up to 128 bytes (one lane or four to a packet) 64, up to 320
 // bytes 32, up to 720 bytes sixteen, up to 1 KiB eight; above 1 KiB see tx_tile_long.  The steps follow what a wave's LDS
 // staging area holds (496-622 chunks of output: 64 packets of up to seven chunks, 32 of up to seventeen, 16 of up to 37,
-// 8 of up to 77) and what measured best where staging does not apply: 100 B 64 against 32 per wave 5.01 / 4.62 TB/s,
-// 128 B the same either way, 200 B better with 32; 280 B 5.30 with 32 (not staged) against 5.22 with 16 (staged), 400 B
+// 8 of up to 77) and what measured best where a tile is staged in part or not at all: 100 B 64 against 32 per wave
+// 5.46 / 4.96 TB/s, 128 B 5.66 / 5.50 (Ethernet: the same either way), 200 B 5.16 / 5.35; 280 B 5.30 with 32 (not staged) against 5.22 with 16 (staged), 400 B
 // 5.23 against 5.73, 700 B 5.62 with 16 against 5.63 with 8, 800 B 5.61 against 5.74, 900 B 5.56 against 5.75.
 inline int tx_tile_for(u64 mean_payload) {
     if (mean_payload > 1024) return tx_tile_long(mean_payload);
     if (mean_payload > 720) return 8;
     if (mean_payload > 320) return 16;
-    return mean_payload <= 104 ? 64 : 32;
+    return mean_payload <= 128 ? 64 : 32;
 }
 
 // Waves per packet of k_tx_build_wave (as a power of two) by mean payload: about three rows of 64 output chunks per wave.
