@@ -187,6 +187,8 @@ struct unet_ctx {
     int device = 0;
     hipStream_t s_comp = nullptr;  // kernels (and D2H of results)
     hipStream_t s_copy = nullptr;  // H2D staging
+    hipStream_t s_down = nullptr;  // unet_tx_build on large batches: packets back to the host while the next payloads go up
+    hipEvent_t tx_up[2] = {nullptr, nullptr}, tx_built[2] = {nullptr, nullptr}, tx_down[2] = {nullptr, nullptr};
     void* pinned[2] = {nullptr, nullptr};
     void* pinned_dev[2] = {nullptr, nullptr};  // the same buffers as the device addresses kernels may use
     uint64_t host_counts[UNET_V_COUNT] = {};   // verdicts of the batches judged in place (added to d_counts by unet_counters)
@@ -203,6 +205,8 @@ struct unet_ctx {
     int tx_wave = 1;              // UNET_TX_WAVE: 0 = every batch goes through the tile kernel, 2 = every batch one packet per wave (A/B, tests)
     u32 tx_wave_block = 256;      // UNET_TXW_BLOCK: threads per workgroup of k_tx_build_wave (64, 128 or 256; more when a packet's group of waves needs it)
     int tx_wave_policy = -1;      // UNET_TXW_POLICY (experiments): cache policy of the two row loads of k_tx_build_wave instead of the choice by mean payload
+    u64 tx_pipeline_min = 16u << 20;  // UNET_TX_PIPELINE_MIN: payload or packet bytes from which unet_tx_build works in overlapping runs
+    bool tx_pipeline = true;      // UNET_TX_PIPELINE=0: unet_tx_build on large batches uploads everything, builds, downloads everything (A/B, tests)
     bool tx_stage = true;         // UNET_TX_STAGE=0: k_tx_build stores every packet straight into the output arena (A/B)
     int tx_group_log2 = -1;       // UNET_TXW_GROUP (1, 2, 4, 8, 16): waves per packet of k_tx_build_wave instead of the choice by mean payload
     bool hdr_plain = false;       // UNET_HDR_PLAIN, read once at unet_open
@@ -388,11 +392,13 @@ inline int check_tiles(u32 n, u32 per_wave) {
 }
 
 // Shared body of the host-pointer batch calls: upload arena + tables, leave device views in `b`.
-int upload_batch(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16, uint32_t stride16,
-                 const uint32_t* len, uint32_t n, Batch* b, u32* mean_len, u32* max_len) {
-    // every record (plus its pad to 16 bytes) must lie inside the caller's arena
-    u64 sum_len = 0;
+// Every record (plus its pad to 16 bytes) must lie inside the caller's arena.  Also: mean and longest length, and
+// whether the records lie in the arena in index order (each one starting at or behind its predecessor).
+int check_records(uint64_t arena_bytes, const uint32_t* off16, uint32_t stride16, const uint32_t* len, uint32_t n, u32* mean_len, u32* max_len,
+                  bool* ascending) {
+    u64 sum_len = 0, prev = 0;
     u32 longest = 0;
+    bool asc = true;
     for (u32 i = 0; i < n; i++) {
         if (len[i] > kMaxLen) return fail(UNET_E_RANGE, "record %u: length %u > 65535", i, len[i]);
         const u64 slot = off16 ? off16[i] : (u64)i * stride16;
@@ -401,10 +407,19 @@ int upload_batch(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const 
         if (end > arena_bytes) return fail(UNET_E_RANGE, "record %u ends at byte %llu, arena is %llu bytes (records are read in 16-byte chunks)", i, (unsigned long long)end, (unsigned long long)arena_bytes);
         sum_len += len[i];
         if (len[i] > longest) longest = len[i];
+        asc = asc && slot >= prev;
+        prev = slot;
     }
     if (mean_len) *mean_len = (u32)(sum_len / n);
     if (max_len) *max_len = longest;
+    if (ascending) *ascending = asc;
+    return UNET_OK;
+}
+
+int upload_batch(unet_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint32_t* off16, uint32_t stride16,
+                 const uint32_t* len, uint32_t n, Batch* b, u32* mean_len, u32* max_len) {
     int rc;
+    if ((rc = check_records(arena_bytes, off16, stride16, len, n, mean_len, max_len, nullptr))) return rc;
     if ((rc = ensure(c, c->d_arena, arena_bytes))) return rc;
     if ((rc = ensure(c, c->d_len, (size_t)n * 4))) return rc;
     if (off16 && (rc = ensure(c, c->d_off, (size_t)n * 4))) return rc;
@@ -571,6 +586,12 @@ int unet_open(int device_id, unet_ctx** out_ctx) {
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_comp, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_down, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipEventCreateWithFlags(&c->tx_up[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->tx_built[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->tx_down[i], hipEventDisableTiming);
+    }
     for (int i = 0; i < 2 && e == hipSuccess; i++) {
         e = hipHostMalloc(&c->pinned[i], kStageBytes, hipHostMallocDefault);
         if (e == hipSuccess) e = hipHostGetDevicePointer(&c->pinned_dev[i], c->pinned[i], 0);
@@ -620,6 +641,8 @@ int unet_open(int device_id, unet_ctx** out_ctx) {
         c->tx_wave_block = v <= 64 ? 64u : (v <= 128 ? 128u : 256u);
     }
     if (const char* t = getenv("UNET_TX_STAGE")) c->tx_stage = atoi(t) != 0;
+    if (const char* t = getenv("UNET_TX_PIPELINE")) c->tx_pipeline = atoi(t) != 0;
+    if (const char* t = getenv("UNET_TX_PIPELINE_MIN")) c->tx_pipeline_min = strtoull(t, nullptr, 10);
     if (const char* t = getenv("UNET_TXW_POLICY")) c->tx_wave_policy = atoi(t);
     if (const char* t = getenv("UNET_TXW_GROUP")) {
         const int v = atoi(t);
@@ -643,12 +666,16 @@ void unet_close(unet_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->s_comp) (void)hipStreamSynchronize(c->s_comp);
     if (c->s_copy) (void)hipStreamSynchronize(c->s_copy);
+    if (c->s_down) (void)hipStreamSynchronize(c->s_down);
     DevBuf* bufs[] = {&c->d_arena, &c->d_off, &c->d_len, &c->d_out, &c->d_aux, &c->d_tx, &c->d_tx_tab, &c->d_tcp, &c->d_len_fill};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < 2; i++) {
         if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
         if (c->pinned_free[i]) (void)hipEventDestroy(c->pinned_free[i]);
+        if (c->tx_up[i]) (void)hipEventDestroy(c->tx_up[i]);
+        if (c->tx_built[i]) (void)hipEventDestroy(c->tx_built[i]);
+        if (c->tx_down[i]) (void)hipEventDestroy(c->tx_down[i]);
     }
     delete c->pool;
     for (auto& sl : c->slot) {
@@ -663,6 +690,7 @@ void unet_close(unet_ctx* c) {
     if (c->copied) (void)hipEventDestroy(c->copied);
     if (c->s_comp) (void)hipStreamDestroy(c->s_comp);
     if (c->s_copy) (void)hipStreamDestroy(c->s_copy);
+    if (c->s_down) (void)hipStreamDestroy(c->s_down);
     delete c;
 }
 
@@ -671,6 +699,7 @@ int unet_sync(unet_ctx* c) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->s_copy));
     HIP_TRY(hipStreamSynchronize(c->s_comp));
+    HIP_TRY(hipStreamSynchronize(c->s_down));
     for (auto& sl : c->slot) HIP_TRY(hipStreamSynchronize(sl.s));
     return UNET_OK;
 }
@@ -1380,6 +1409,95 @@ int unet_tx_layout(const uint32_t* payload_len, uint32_t n, int mode, uint32_t* 
     return unet_tx_layout_aligned(payload_len, n, mode, 1, out_off16, out_arena_bytes);
 }
 
+// unet_tx_build on a batch too large for one staging image, its payloads in index order in the caller's arena: the
+// batch is cut into runs of packets whose payloads and whose packets each fit half a pinned buffer; while run k is built,
+// run k + 1's payloads travel up (pinned[0], two halves in turn, copy stream) and run k - 1's packets travel down
+// (pinned[1], two halves, a stream of their own) -- the host link carries both directions at once, and the caller's
+// thread copies into and out of the pinned halves in between.  (Packets copied by the runtime straight into the
+// caller's pageable memory come back at a third of the link's rate: 262,144 datagrams of 1472 bytes took 31 ms that
+// way, 8 of them going up.)  The tables go up first and come back last, as in the unpipelined form.
+int tx_build_pipelined(unet_ctx* c, const uint8_t* payload_arena, uint64_t payload_arena_bytes, const uint32_t* payload_off16,
+                       uint32_t payload_stride16, const uint32_t* payload_len, const unet_tx_desc* desc, uint32_t n, const unet_iface* iface,
+                       uint8_t* out_arena, uint64_t need, const uint32_t* out_off16, uint32_t* out_len, uint8_t* status) {
+    // bytes per run and direction: half a pinned buffer, less for batches of a few MiB so that they still make six runs or more
+    const u64 larger = payload_arena_bytes > need ? payload_arena_bytes : need;
+    u64 kHalf = (larger / 6u + (1u << 20) - 1u) & ~(u64)((1u << 20) - 1u);
+    kHalf = kHalf < (1u << 20) ? (1u << 20) : (kHalf > kStageBytes / 2 ? kStageBytes / 2 : kHalf);
+    int rc;
+    if ((rc = ensure(c, c->d_arena, payload_arena_bytes))) return rc;
+    if ((rc = ensure(c, c->d_len, (size_t)n * 4))) return rc;
+    if (payload_off16 && (rc = ensure(c, c->d_off, (size_t)n * 4))) return rc;
+    const size_t o_desc = 0, o_off = (size_t)n * sizeof(unet_tx_desc), o_len = o_off + (size_t)n * 4, o_st = o_len + (size_t)n * 4;
+    if ((rc = ensure(c, c->d_tx_tab, o_st + n))) return rc;
+    if ((rc = ensure(c, c->d_tx, need))) return rc;
+    char* tab = (char*)c->d_tx_tab.p;
+    if ((rc = h2d(c, c->d_len.p, payload_len, (size_t)n * 4))) return rc;
+    if (payload_off16 && (rc = h2d(c, c->d_off.p, payload_off16, (size_t)n * 4))) return rc;
+    if ((rc = h2d(c, tab + o_desc, desc, (size_t)n * sizeof(unet_tx_desc)))) return rc;
+    if ((rc = h2d(c, tab + o_off, out_off16, (size_t)n * 4))) return rc;
+    if ((rc = copies_before_compute(c))) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_tx.p, 0, need, c->s_comp));  // refused packets leave their slots untouched
+    HIP_TRY(hipEventSynchronize(c->pinned_free[0]));        // the table uploads are through with the pinned buffers
+    HIP_TRY(hipEventSynchronize(c->pinned_free[1]));
+    auto slot_of = [&](u32 i) { return payload_off16 ? (u64)payload_off16[i] : (u64)i * payload_stride16; };
+    auto out_at = [&](u32 i) { return i < n ? (u64)out_off16[i] * 16u : need; };
+    struct Run { u32 a, b; u64 in_lo, in_hi; };
+    Run prev{0, 0, 0, 0};
+    u32 k = 0;
+    for (u32 a = 0; a < n; ++k) {
+        // packets a .. b-1: as many as keep both byte ranges within half a pinned buffer (one packet always fits)
+        Run r{a, a, slot_of(a) * 16u, slot_of(a) * 16u};
+        while (r.b < n) {
+            const u64 end = slot_of(r.b) * 16u + (((u64)payload_len[r.b] + 15u) & ~15ull);
+            const u64 hi = end > r.in_hi ? end : r.in_hi;
+            if (r.b > a && (hi - r.in_lo > kHalf || out_at(r.b + 1u) - out_at(a) > kHalf)) break;
+            r.in_hi = hi;
+            ++r.b;
+        }
+        const int h = (int)(k & 1u);
+        uint8_t* up = (uint8_t*)c->pinned[0] + (size_t)h * kHalf;
+        if (k >= 2u) HIP_TRY(hipEventSynchronize(c->tx_up[h]));  // run k - 2 has left this half
+        if (r.in_hi > r.in_lo) {
+            c->pool->copy(up, payload_arena + r.in_lo, (size_t)(r.in_hi - r.in_lo));
+            HIP_TRY(hipMemcpyAsync((char*)c->d_arena.p + r.in_lo, up, (size_t)(r.in_hi - r.in_lo), hipMemcpyHostToDevice, c->s_copy));
+        }
+        HIP_TRY(hipEventRecord(c->tx_up[h], c->s_copy));
+        HIP_TRY(hipStreamWaitEvent(c->s_comp, c->tx_up[h], 0));
+        {
+            // (with a fixed stride the kernel finds packet i at i strides from the arena it is given)
+            const u64 skip = payload_off16 ? 0u : (u64)r.a * payload_stride16 * 16u;
+            rc = unet_tx_build_dev(c, nullptr, (const uint8_t*)c->d_arena.p + skip, payload_arena_bytes - skip,
+                                   payload_off16 ? (const uint32_t*)c->d_off.p + r.a : nullptr, payload_stride16, (const uint32_t*)c->d_len.p + r.a,
+                                   (const unet_tx_desc*)(tab + o_desc) + r.a, r.b - r.a, iface, (uint8_t*)c->d_tx.p, need,
+                                   (const uint32_t*)(tab + o_off) + r.a, (uint32_t*)(tab + o_len) + r.a, (uint8_t*)(tab + o_st) + r.a);
+            if (rc) {
+                (void)hipStreamSynchronize(c->s_copy);
+                (void)hipStreamSynchronize(c->s_down);
+                return rc;
+            }
+        }
+        HIP_TRY(hipEventRecord(c->tx_built[h], c->s_comp));
+        HIP_TRY(hipStreamWaitEvent(c->s_down, c->tx_built[h], 0));
+        // (this half's previous contents, run k - 2's packets, were copied out below while run k - 1 was in flight)
+        HIP_TRY(hipMemcpyAsync((uint8_t*)c->pinned[1] + (size_t)h * kHalf, (const uint8_t*)c->d_tx.p + out_at(r.a), (size_t)(out_at(r.b) - out_at(r.a)),
+                               hipMemcpyDeviceToHost, c->s_down));
+        HIP_TRY(hipEventRecord(c->tx_down[h], c->s_down));
+        if (k >= 1u) {
+            HIP_TRY(hipEventSynchronize(c->tx_down[h ^ 1]));
+            c->pool->copy(out_arena + out_at(prev.a), (const uint8_t*)c->pinned[1] + (size_t)(h ^ 1) * kHalf, (size_t)(out_at(prev.b) - out_at(prev.a)));
+        }
+        prev = r;
+        a = r.b;
+    }
+    const int hl = (int)((k - 1u) & 1u);
+    HIP_TRY(hipEventSynchronize(c->tx_down[hl]));
+    c->pool->copy(out_arena + out_at(prev.a), (const uint8_t*)c->pinned[1] + (size_t)hl * kHalf, (size_t)(out_at(prev.b) - out_at(prev.a)));
+    HIP_TRY(hipStreamSynchronize(c->s_copy));
+    if ((rc = d2h_sync(c, out_len, tab + o_len, (size_t)n * 4))) return rc;
+    if (status && (rc = d2h_sync(c, status, tab + o_st, (size_t)n))) return rc;
+    return UNET_OK;
+}
+
 int unet_tx_build(unet_ctx* c, const uint8_t* payload_arena, uint64_t payload_arena_bytes, const uint32_t* payload_off16,
                   uint32_t payload_stride16, const uint32_t* payload_len, const unet_tx_desc* desc, uint32_t n,
                   const unet_iface* iface, uint8_t* out_arena, uint64_t out_arena_bytes, uint32_t* out_off16,
@@ -1403,7 +1521,13 @@ int unet_tx_build(unet_ctx* c, const uint8_t* payload_arena, uint64_t payload_ar
         const u64 in_off = tab, in_ooff = 2u * tab, in_desc = 3u * tab, in_arena = in_desc + dtab, in_total = in_arena + im.used;
         const u64 o_len = 0, o_st = tab, o_arena = (tab + (((u64)n + 15u) & ~15ull) + 255u) & ~255ull, o_total = o_arena + need;
         const bool in_place = in_total <= kTxInPlaceBytes && o_total <= kTxInPlaceBytes && in_total <= c->zero_copy_bytes;
-        if (in_place || (in_total <= kStageBytes && o_total <= kStageBytes)) {
+        // From 16 MiB up a batch in index order is better cut into runs that overlap the two directions of the host
+        // link (tx_build_pipelined) than sent as one image each way: 16,384 datagrams of 1472 bytes 1.55 -> 1.30 ms,
+        // 32,768 4.4 -> 2.4 ms; 8192 the same either way, 4096 0.44 ms as one image against 0.70 in runs.
+        bool as_runs = false;
+        if (!in_place && c->tx_pipeline && (im.used >= c->tx_pipeline_min || need >= c->tx_pipeline_min))
+            if ((rc = check_records(payload_arena_bytes, payload_off16, payload_stride16, payload_len, n, nullptr, nullptr, &as_runs))) return rc;
+        if (!as_runs && (in_place || (in_total <= kStageBytes && o_total <= kStageBytes))) {
             // (larger batches that still fit the pinned buffers: the same two images, one copy command each way)
             HIP_TRY(hipEventSynchronize(c->pinned_free[0]));
             HIP_TRY(hipEventSynchronize(c->pinned_free[1]));
@@ -1443,6 +1567,13 @@ int unet_tx_build(unet_ctx* c, const uint8_t* payload_arena, uint64_t payload_ar
     }
     Batch b;
     u32 mean = 0, maxlen = 0;
+    bool ascending = false;
+    if ((rc = check_records(payload_arena_bytes, payload_off16, payload_stride16, payload_len, n, &mean, &maxlen, &ascending))) return rc;
+    if (ascending && c->tx_pipeline) {
+        LenScope hint(c, mean, maxlen);
+        return tx_build_pipelined(c, payload_arena, payload_arena_bytes, payload_off16, payload_stride16, payload_len, desc, n, iface, out_arena, need,
+                                  out_off16, out_len, status);
+    }
     if ((rc = upload_batch(c, payload_arena, payload_arena_bytes, payload_off16, payload_stride16, payload_len, n, &b, &mean, &maxlen))) return rc;
     LenScope hint(c, mean, maxlen);
     // tables: descriptors | output offsets | output lengths | status
