@@ -1416,9 +1416,25 @@ int unet_tx_layout(const uint32_t* payload_len, uint32_t n, int mode, uint32_t* 
 // thread copies into and out of the pinned halves in between.  (Packets copied by the runtime straight into the
 // caller's pageable memory come back at a third of the link's rate: 262,144 datagrams of 1472 bytes took 31 ms that
 // way, 8 of them going up.)  The tables go up first and come back last, as in the unpipelined form.
+int tx_build_runs(unet_ctx* c, const uint8_t* payload_arena, uint64_t payload_arena_bytes, const uint32_t* payload_off16,
+                  uint32_t payload_stride16, const uint32_t* payload_len, const unet_tx_desc* desc, uint32_t n, const unet_iface* iface,
+                  uint8_t* out_arena, uint64_t need, const uint32_t* out_off16, uint32_t* out_len, uint8_t* status);
 int tx_build_pipelined(unet_ctx* c, const uint8_t* payload_arena, uint64_t payload_arena_bytes, const uint32_t* payload_off16,
                        uint32_t payload_stride16, const uint32_t* payload_len, const unet_tx_desc* desc, uint32_t n, const unet_iface* iface,
                        uint8_t* out_arena, uint64_t need, const uint32_t* out_off16, uint32_t* out_len, uint8_t* status) {
+    const int rc = tx_build_runs(c, payload_arena, payload_arena_bytes, payload_off16, payload_stride16, payload_len, desc, n, iface, out_arena, need,
+                                 out_off16, out_len, status);
+    if (rc) {
+        // nothing may still be reading or writing the pinned halves when the next call starts (g_err keeps this failure's text)
+        (void)hipStreamSynchronize(c->s_copy);
+        (void)hipStreamSynchronize(c->s_comp);
+        (void)hipStreamSynchronize(c->s_down);
+    }
+    return rc;
+}
+int tx_build_runs(unet_ctx* c, const uint8_t* payload_arena, uint64_t payload_arena_bytes, const uint32_t* payload_off16,
+                  uint32_t payload_stride16, const uint32_t* payload_len, const unet_tx_desc* desc, uint32_t n, const unet_iface* iface,
+                  uint8_t* out_arena, uint64_t need, const uint32_t* out_off16, uint32_t* out_len, uint8_t* status) {
     // bytes per run and direction: half a pinned buffer, less for batches of a few MiB so that they still make six runs or more
     const u64 larger = payload_arena_bytes > need ? payload_arena_bytes : need;
     u64 kHalf = (larger / 6u + (1u << 20) - 1u) & ~(u64)((1u << 20) - 1u);
@@ -1470,11 +1486,7 @@ int tx_build_pipelined(unet_ctx* c, const uint8_t* payload_arena, uint64_t paylo
                                    payload_off16 ? (const uint32_t*)c->d_off.p + r.a : nullptr, payload_stride16, (const uint32_t*)c->d_len.p + r.a,
                                    (const unet_tx_desc*)(tab + o_desc) + r.a, r.b - r.a, iface, (uint8_t*)c->d_tx.p, need,
                                    (const uint32_t*)(tab + o_off) + r.a, (uint32_t*)(tab + o_len) + r.a, (uint8_t*)(tab + o_st) + r.a);
-            if (rc) {
-                (void)hipStreamSynchronize(c->s_copy);
-                (void)hipStreamSynchronize(c->s_down);
-                return rc;
-            }
+            if (rc) return rc;
         }
         HIP_TRY(hipEventRecord(c->tx_built[h], c->s_comp));
         HIP_TRY(hipStreamWaitEvent(c->s_down, c->tx_built[h], 0));
