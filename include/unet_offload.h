@@ -119,7 +119,10 @@ typedef struct unet_ctx unet_ctx;
  * Host-pointer calls on small batches (staging image up to 4 MiB for unet_verify, unet_verify_async,
  * unet_generate, unet_ipv4_validate and unet_csum_batch, 1 MiB for unet_tx_build, 64 KiB for unet_csum) let the kernel read the pinned staging buffer in
  * place across the host link and write its results into pinned memory: one launch and one wait per call, no copy
- * command.  Larger batches are copied to device memory first.  Environment, read once here: UNET_ZERO_COPY_BYTES
+ * command.  Larger batches are copied to device memory first -- through the library's pinned staging buffers, or, from
+ * 1 MiB up and for the synchronous calls other than unet_tx_build, straight from the caller's arena when that is
+ * pinned host memory itself (hipHostMalloc, or registered with hipHostRegister), which takes the caller's thread out of
+ * the transfer (unet_verify on 262,144 x 1500 bytes: 48 -> 53 GB/s).  Environment, read once here: UNET_ZERO_COPY_BYTES
  * (that limit; 0 = always copy), UNET_COPY_THREADS (host threads filling the staging buffers, default 4), and for
  * experiments UNET_TILE / UNET_TX_TILE (records / packets per wave, overriding the library's choice by record size),
  * UNET_TX_WAVE (0: long payloads by tiles too; 2: every batch one packet per wavefront), UNET_TXW_GROUP (wavefronts per

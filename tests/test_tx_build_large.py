@@ -106,3 +106,40 @@ def test_large_batches_pipelined_and_not(case):
                 assert (got[~built] == 0).all()  # pads, and the slots of refused packets
         finally:
             close_checked(ctx)
+
+
+def test_large_batches_from_and_into_pinned_memory():
+    """Payload arena and packet arena allocated as pinned host memory by the caller (here: torch's pinned tensors):
+    unet_tx_build and unet_verify copy straight from and into them.  Same bytes as through the staging buffers; one
+    arena pinned and the other not works too."""
+    import torch
+    from conftest import close_checked
+    rng = np.random.default_rng(77)
+    mode = unet_amd.MODE_L3
+    ifc = unet_amd.Iface("192.0.2.2", "255.255.255.0", mac=bytes.fromhex("02aabbccddee"), mode=mode)
+    plen = np.asarray(rng.choice([36, 548, 1472, 8972], p=[.3, .3, .3, .1], size=30000), dtype=np.uint32)
+    arena, off16, stride16 = _layout(rng, plen, "packed")
+    desc = _descs(rng, len(plen), ifc)
+    ooff, obytes = tx_out_layout(plen, mode)
+    exp, exp_len, exp_status = O.tx_build_batch(arena, off16, plen, desc, ifc, ooff, obytes)
+    built = np.zeros(obytes, dtype=bool)
+    for o, l in zip(ooff[exp_status == 0], exp_len[exp_status == 0]):
+        built[int(o) * 16:int(o) * 16 + int(l)] = True
+    t_in = torch.empty(arena.nbytes, dtype=torch.uint8).pin_memory()
+    t_out = torch.empty(obytes + 4096, dtype=torch.uint8).pin_memory()
+    pinned_in, pinned_out = t_in.numpy(), t_out.numpy()
+    pinned_in[:] = arena
+    plain_out = np.empty(obytes + 4096, dtype=np.uint8)
+    ctx = unet_amd.Offload(0)
+    try:
+        for src, dst in ((pinned_in, pinned_out), (pinned_in, plain_out), (arena, pinned_out)):
+            dst[:] = 0xAB
+            got, got_off, got_len, got_status = ctx.tx_build(src, off16, plen, desc, ifc, out=dst)
+            assert (got_status == exp_status).all() and (got_len == exp_len).all() and (got_off == ooff).all()
+            assert (got[built] == exp[built]).all() and (got[~built] == 0).all()
+            assert (dst[obytes:] == 0xAB).all()
+            # the packets just built, judged where they lie (a pinned arena read by unet_verify)
+            res = ctx.verify(dst[:obytes], ooff, exp_len, ifc)
+            assert (res == O.recv_batch(got.copy(), ooff, exp_len, ifc)).all()
+    finally:
+        close_checked(ctx)

@@ -539,15 +539,20 @@ class Offload:
         return arena, status
 
     def tx_build(self, payload_arena: np.ndarray, payload_off16, payload_lens: np.ndarray, desc: np.ndarray, iface: Iface,
-                 payload_stride16: int = 0):
-        """Returns (packet arena, out_off16, out_len, status)."""
+                 payload_stride16: int = 0, out: Optional[np.ndarray] = None):
+        """Returns (packet arena, out_off16, out_len, status).  `out`: the caller's packet arena (at least as large as
+        unet_tx_layout says) instead of a fresh one."""
         arena, off16, lens = self._prep(payload_arena, payload_off16, payload_lens)
         desc = np.ascontiguousarray(desc)
         assert desc.dtype.itemsize == 28 and len(desc) == len(lens)
         n = len(lens)
         need = C.c_uint64(0)
         _check(self.lib.unet_tx_layout(_np_ptr(lens), n, int(iface.mode), None, C.byref(need)))
-        out = _aligned_u8(need.value)
+        if out is None:
+            out = _aligned_u8(need.value)
+        else:
+            assert out.dtype == np.uint8 and out.flags.c_contiguous and out.nbytes >= need.value and out.ctypes.data % 16 == 0
+            out = out[:need.value]
         out_off = np.zeros(n, dtype=np.uint32)
         out_len = np.zeros(n, dtype=np.uint32)
         status = np.zeros(n, dtype=np.uint8)

@@ -249,8 +249,30 @@ int ensure(unet_ctx* c, DevBuf& b, size_t bytes) {
     return UNET_OK;
 }
 
-// Host -> device through the two pinned buffers, on the copy stream.
+// Is [p, p + bytes) host memory the copy engines reach directly -- allocated as pinned memory by the caller
+// (hipHostMalloc) or registered by it (hipHostRegister)?  Asked for large transfers only: the answer costs a
+// microsecond or two.
+constexpr size_t kDirectMin = 1u << 20;
+inline bool caller_pinned(const void* p, size_t bytes) {
+    if (bytes < kDirectMin) return false;
+    for (const char* q : {(const char*)p, (const char*)p + bytes - 1}) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) {
+            (void)hipGetLastError();  // (older runtimes answer "invalid value" for ordinary host memory)
+            return false;
+        }
+        if (a.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+
+// Host -> device on the copy stream: through the two pinned buffers, or straight from the caller's memory when that is
+// pinned itself (every caller of this waits for the copy stream before it returns).
 int h2d(unet_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (caller_pinned(src, bytes)) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->s_copy));
+        return UNET_OK;
+    }
     size_t off = 0;
     int which = 0;
     while (off < bytes) {
@@ -1455,6 +1477,9 @@ int tx_build_runs(unet_ctx* c, const uint8_t* payload_arena, uint64_t payload_ar
     HIP_TRY(hipMemsetAsync(c->d_tx.p, 0, need, c->s_comp));  // refused packets leave their slots untouched
     HIP_TRY(hipEventSynchronize(c->pinned_free[0]));        // the table uploads are through with the pinned buffers
     HIP_TRY(hipEventSynchronize(c->pinned_free[1]));
+    // (Arenas that are pinned memory of the caller's own go through the halves all the same: copied straight from and
+    // into them the same batch took 16.7 ms against 16.2 -- the two directions of the link do not overlap on this
+    // platform, so the staging copies, which run beside the transfers, cost nothing.)
     auto slot_of = [&](u32 i) { return payload_off16 ? (u64)payload_off16[i] : (u64)i * payload_stride16; };
     auto out_at = [&](u32 i) { return i < n ? (u64)out_off16[i] * 16u : need; };
     struct Run { u32 a, b; u64 in_lo, in_hi; };
@@ -1504,6 +1529,7 @@ int tx_build_runs(unet_ctx* c, const uint8_t* payload_arena, uint64_t payload_ar
     const int hl = (int)((k - 1u) & 1u);
     HIP_TRY(hipEventSynchronize(c->tx_down[hl]));
     c->pool->copy(out_arena + out_at(prev.a), (const uint8_t*)c->pinned[1] + (size_t)hl * kHalf, (size_t)(out_at(prev.b) - out_at(prev.a)));
+    HIP_TRY(hipStreamSynchronize(c->s_down));
     HIP_TRY(hipStreamSynchronize(c->s_copy));
     if ((rc = d2h_sync(c, out_len, tab + o_len, (size_t)n * 4))) return rc;
     if (status && (rc = d2h_sync(c, status, tab + o_st, (size_t)n))) return rc;
