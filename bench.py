@@ -615,8 +615,18 @@ def main():
     def read_records(buf, nbytes, sink, s):
         ctx.stream_read_records_dev(buf, nbytes, rec_bytes, sink, s)
 
-    for name, fn in (("slabs", ctx.stream_read_dev), ("pieces", ctx.stream_read_pieces_dev), ("pieces_full_occupancy", ctx.stream_read_pieces_full_dev),
-                     ("records", read_records)):
+    yardsticks = [("slabs", ctx.stream_read_dev), ("pieces", ctx.stream_read_pieces_dev), ("pieces_full_occupancy", ctx.stream_read_pieces_full_dev),
+                  ("records", read_records)]
+    if op not in ("txbuild", "tximix", "eth1514") and b0.kind != unet_amd.SYNTH_IPV4_HDR20 and getattr(b0, "len", None) is not None:
+        # and the batch's own records through the checksum-only kernel (k_csum: the record kernels' requests, head and tail
+        # rows and all, a sum and two bytes written per record, no parse): what the access pattern itself allows
+        d_sums = torch.empty(b0.n, dtype=torch.int16, device="cuda")
+
+        def read_record_sums(buf, nbytes, sink, s):
+            ctx.csum_batch_dev(buf, nbytes, None if b0.stride16 else b0.off.data_ptr(), b0.stride16, b0.len.data_ptr(), None, b0.n, d_sums.data_ptr(), s)
+
+        yardsticks.append(("record_sums", read_record_sums))
+    for name, fn in yardsticks:
         t_warm = time.perf_counter()
         while time.perf_counter() - t_warm < 0.03:
             fn(b0.arena.data_ptr(), b0.nbytes, d_sink.data_ptr(), stream)
