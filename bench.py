@@ -610,7 +610,7 @@ def main():
     # The epilogue above leaves the GPU idle for milliseconds and its clocks drop: each shape is warmed up for 30 ms
     # first, and -- this being a ceiling -- the fastest of three groups of eight launches counts.
     shapes = {}
-    rec_bytes = max(16, min(65535, b0.nbytes // max(1, b0.n)))  # the batch's mean record size, for the third shape
+    rec_bytes = max(16, min(65520, b0.nbytes // max(1, b0.n)))  # the batch's mean record size, for the third shape
 
     def read_records(buf, nbytes, sink, s):
         ctx.stream_read_records_dev(buf, nbytes, rec_bytes, sink, s)

@@ -504,7 +504,7 @@ int unet_stream_read_pieces_dev(unet_ctx* ctx, void* stream, const uint8_t* d_bu
  * CU, which reads faster on most GPUs of this type and slower on some). */
 int unet_stream_read_pieces_full_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t bytes,
                                      uint32_t* d_sink);
-/* A third shape: the buffer read as packed records of `record_bytes` each (rounded up to 16), sixteen to a wavefront,
+/* A third shape: the buffer read as packed records of `record_bytes` each (1..65520, rounded up to 16), sixteen to a wavefront,
  * with the loads the record kernels issue -- whole streaming rows and one cached row holding the record's end -- and
  * only a sum taken.  (A measurement aid: it keeps a table of n equal lengths in the context and may allocate it.) */
 int unet_stream_read_records_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t bytes, uint32_t record_bytes,

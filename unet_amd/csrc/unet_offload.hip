@@ -2000,7 +2000,8 @@ int unet_stream_read_pieces_full_dev(unet_ctx* ctx, void* stream, const uint8_t*
 int unet_stream_read_records_dev(unet_ctx* ctx, void* stream, const uint8_t* d_buf, uint64_t bytes, uint32_t record_bytes, uint32_t* d_sink) {
     if (!ctx || !d_buf || !d_sink) return fail(UNET_E_INVAL, "null argument");
     if (((uintptr_t)d_buf & 15u) != 0) return fail(UNET_E_INVAL, "buffer must be 16-byte aligned");
-    if (record_bytes == 0 || record_bytes > kMaxLen) return fail(UNET_E_RANGE, "record size %u: 1..65535 bytes", record_bytes);
+    // (rounded up to 16 bytes a record may not be longer than the longest record the kernels take, 65535 bytes)
+    if (record_bytes == 0 || record_bytes > 65520u) return fail(UNET_E_RANGE, "record size %u: 1..65520 bytes", record_bytes);
     const u32 stride16 = (record_bytes + 15u) / 16u;
     const u64 nrec = bytes / 16 / stride16;
     if (nrec == 0) return UNET_OK;
