@@ -1821,6 +1821,7 @@ int unet_flow_hash_dev(unet_ctx* ctx, void* stream, const uint8_t* d_arena, uint
     if (rc) return rc;
     if (n == 0) return UNET_OK;
     if (!iface || !d_hash) return fail(UNET_E_INVAL, "null iface or output");
+    if (iface->mode != UNET_MODE_L3 && iface->mode != UNET_MODE_L2) return fail(UNET_E_INVAL, "bad iface mode %d", iface->mode);
     HIP_TRY(hipSetDevice(ctx->device));
     Batch b{d_arena, arena_bytes, d_off16, stride16, d_len, n};
     const u32 grid = (n + kBlock - 1) / kBlock;
