@@ -171,7 +171,8 @@ def dev_round(ctx, seed):
     frames = make_frames(rng, n, ifc)
     arena, off16, stride16, lens, how = layout(rng, frames)
     hint = int(rng.choice([0, 0, max(1, int(lens.mean())), 40, 300, 1500, 9000, 60000]))
-    tag = (seed, n, mode, how, int(lens.max()), round(float(lens.mean()), 1), hint)
+    max_hint = int(rng.choice([0, 0, 0, max(1, int(lens.max())), 64, 80, 96, 1000]))  # right, absent or wrong: the verdicts may not depend on it
+    tag = (seed, n, mode, how, int(lens.max()), round(float(lens.mean()), 1), hint, max_hint)
     dev = torch.device("cuda:0")
     d_arena = torch.from_numpy(arena).to(dev)
     d_off = None if off16 is None else torch.from_numpy(off16.view(np.int32)).to(dev)
@@ -180,6 +181,7 @@ def dev_round(ctx, seed):
     d_res = torch.empty(n, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     ctx.hint_mean_len(hint)
+    ctx.hint_max_len(max_hint)
     try:
         ctx.verify_dev(d_arena.data_ptr(), arena.nbytes, p_off, stride16, d_len.data_ptr(), n, ifc, d_res.data_ptr())
         seeds = rng.integers(0, 65536, size=n).astype(np.uint16)
@@ -205,6 +207,7 @@ def dev_round(ctx, seed):
             assert (d_arena.cpu().numpy() == ea).all(), ("generate_dev bytes", tag)
     finally:
         ctx.hint_mean_len(0)
+        ctx.hint_max_len(0)
     return tag
 
 
