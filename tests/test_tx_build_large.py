@@ -143,3 +143,28 @@ def test_large_batches_from_and_into_pinned_memory():
             assert (res == O.recv_batch(got.copy(), ooff, exp_len, ifc)).all()
     finally:
         close_checked(ctx)
+
+
+def test_large_host_batches_through_the_receive_and_fill_entry_points():
+    """unet_verify, unet_csum_batch and unet_generate on a 60 MB batch from pageable memory (uploaded through the pinned
+    staging buffers, two at a time) and from pinned memory of the caller's own (uploaded as it lies), against the oracle."""
+    import torch
+    from conftest import close_checked
+    ifc = unet_amd.Iface("192.0.2.2", "255.255.255.0", ext_tcp=True)
+    arena, off16, lens = unet_amd.synth_host(unet_amd.SYNTH_IMIX, 4242, 0, 100000, ifc)
+    assert arena.nbytes > (40 << 20)
+    t_pinned = torch.from_numpy(arena).pin_memory()
+    rng = np.random.default_rng(3)
+    seeds = rng.integers(0, 65536, size=len(lens)).astype(np.uint16)
+    want = O.recv_batch(arena, off16, lens, ifc)
+    want_sums = O.csum_batch(arena, off16, lens, seeds)
+    want_filled, want_status = O.generate_batch(arena, off16, lens)
+    ctx = unet_amd.Offload(0)
+    try:
+        for src in (arena, t_pinned.numpy()):
+            assert np.array_equal(ctx.verify(src, off16, lens, ifc), want)
+            assert np.array_equal(ctx.csum_batch(src, off16, lens, seeds), want_sums)
+            filled, status = ctx.generate(src, off16, lens)
+            assert np.array_equal(status, want_status) and np.array_equal(filled, want_filled)
+    finally:
+        close_checked(ctx)
