@@ -33,3 +33,32 @@ def test_fuzz_transmit_rounds_per_kernel_configuration(knobs):
             tx_dev_round(ctx, seed)
     finally:
         close_checked(ctx)
+
+
+def test_fuzz_rounds_from_two_threads_with_a_context_each():
+    """Contexts are thread-compatible: two threads, each with a context of its own on the same GPU, run transmit and
+    device-pointer rounds at the same time (the binding releases the interpreter lock inside every call)."""
+    import threading
+    from conftest import close_checked
+    ctxs = [unet_amd.Offload(0), unet_amd.Offload(0)]
+    errors = []
+
+    def worker(k):
+        try:
+            for seed in range(3000 + 100 * k, 3000 + 100 * k + 25):
+                tx_round(ctxs[k], seed)
+                dev_round(ctxs[k], seed)
+                tx_dev_round(ctxs[k], seed)
+        except BaseException as e:  # noqa: BLE001 -- reported below, in the main thread
+            errors.append((k, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    try:
+        assert not errors, errors
+    finally:
+        for c in ctxs:
+            close_checked(c)
