@@ -24,7 +24,7 @@ class ResultC(C.Structure):
 
 
 def build():
-    subprocess.check_call(["make", "-s", "-C", _HERE])
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
 
 
 _lib = None
