@@ -232,3 +232,17 @@ def test_arena_packers():
         F.pack_length_prefixed(struct.pack("<I", 9) + b"abc")
     with pytest.raises(unet_amd.UnetError, match="65535"):
         F.pack_length_prefixed(struct.pack("<I", 70000) + bytes(70000))
+
+
+def test_public_header_compiles_as_c99_c11_and_cpp11(tmp_path):
+    """include/unet_offload.h is what a C, C++ or (through bindgen-style declarations) Rust caller binds against: it must
+    be a valid header in each dialect by itself, pedantic warnings as errors."""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "unet_offload.h")
+    src.write_text(f'#include "{hdr}"\nint main(void) {{ unet_iface i; unet_result r; unet_tx_desc d; (void)i; (void)r; (void)d; '
+                   'return (int)sizeof(unet_tx_desc) - 28 + (int)sizeof(unet_result) - 4; }\n')
+    for cc, flags in (("gcc", ["-std=c99"]), ("gcc", ["-std=c11", "-Wstrict-prototypes"]), ("g++", ["-std=c++11", "-x", "c++"])):
+        p = subprocess.run([cc, *flags, "-Wall", "-Wextra", "-pedantic", "-Werror", "-c", str(src), "-o", str(tmp_path / "hdr.o")],
+                           capture_output=True, text=True)
+        assert p.returncode == 0, (cc, flags, p.stderr)
