@@ -766,3 +766,61 @@ def test_full_size_header_batch(offload):
     assert (d_arena.cpu().numpy()[:n * 20] == h_arena[:n * 20]).all()
     exp = O.ipv4_validate_batch(h_arena[:n * 20])
     assert (results_to_numpy(d_out) == exp).all()
+
+
+@pytest.mark.parametrize("mode", [unet_amd.MODE_L3, unet_amd.MODE_L2])
+def test_full_size_mixed_payloads_built_then_every_packet_against_oracle(offload, mode):
+    """The transmit benchmark's mixed batch at its full size: 8,388,608 payloads of 36-8972 bytes (the IMIX packet sizes
+    less their headers) built into packets (L3) or frames (L2) by unet_tx_build_dev, a few descriptors refused; the
+    CPU oracle then receives every built packet where it lies -- header and datagram checksums, lengths, padding -- and
+    its verdicts must be the GPU's, and the accepted ones exactly the packets that were built for this receiver."""
+    torch = torch_mod()
+    from unet_amd._ffi import TX_DESC_DTYPE, tx_out_layout
+    n = 1 << 23
+    rng = np.random.default_rng(99)
+    tx = unet_amd.Iface("192.0.2.2", "255.255.255.0", mac=bytes.fromhex("02aabbccddee"), mode=mode)
+    rx = unet_amd.Iface("198.51.100.7", "255.255.255.0", mac=bytes.fromhex("02c0ffee0007"), mode=mode)
+    plen = rng.choice(np.array([36, 548, 1472, 4068, 8972], dtype=np.uint32), p=[.56, .32, .08, .02, .02], size=n)
+    slots = (plen.astype(np.int64) + 15) // 16
+    poff = (np.cumsum(slots) - slots).astype(np.uint32)
+    pbytes = int(slots.sum()) * 16
+    g = torch.Generator(device="cuda").manual_seed(7)
+    d_pay = torch.randint(0, 2**31 - 1, (pbytes // 4,), dtype=torch.int32, device="cuda", generator=g).view(torch.uint8)
+    desc = np.zeros(n, dtype=TX_DESC_DTYPE)
+    desc["src"], desc["dst"], desc["proto"] = tx.unicast, rx.unicast, 17
+    icmp = np.arange(n) % 7 == 3
+    desc["proto"][icmp] = 1
+    desc["l4a"] = np.where(icmp, 0x0800, np.arange(n) & 0xFFFF)
+    desc["l4b"], desc["ip_id"] = 53, np.arange(n) & 0xFFFF
+    desc["values"] = np.arange(n, dtype=np.uint32) * 2654435761 & 0xFFFFFFFF
+    desc["dst_mac"] = np.frombuffer(bytes(rx.mac), dtype=np.uint8)
+    elsewhere = np.arange(n) % 1000 == 17   # addressed to another host: built all the same, ignored by this receiver
+    desc["dst"][elsewhere] = 0x0A000001
+    refused = np.arange(n) % 4099 == 11     # not UDP or ICMP: the slot stays as it was
+    desc["proto"][refused] = 99
+    ooff, obytes = tx_out_layout(plen, mode)
+    d_out = torch.zeros(obytes, dtype=torch.uint8, device="cuda")
+    d_olen = torch.zeros(n, dtype=torch.int32, device="cuda")
+    d_st = torch.full((n,), 0xEE, dtype=torch.uint8, device="cuda")
+    d_poff, d_plen, d_ooff, d_desc = dev(poff), dev(plen), dev(ooff), dev(desc.view(np.uint8).reshape(-1))
+    offload.tx_build_dev(d_pay.data_ptr(), pbytes, d_poff.data_ptr(), 0, d_plen.data_ptr(), d_desc.data_ptr(), n, tx, d_out.data_ptr(), obytes,
+                         d_ooff.data_ptr(), d_olen.data_ptr(), d_st.data_ptr(), stream())
+    torch.cuda.synchronize()
+    st = d_st.cpu().numpy()
+    olen = d_olen.cpu().numpy().view(np.uint32)
+    assert (st[refused] == 1).all() and (st[~refused] == 0).all()
+    l3 = plen.astype(np.int64) + 28
+    want_len = np.where(refused, 0, l3 if mode == unet_amd.MODE_L3 else 14 + np.maximum(l3, 60))
+    assert (olen == want_len).all()
+    d_res = torch.zeros(n, dtype=torch.int32, device="cuda")
+    offload.verify_dev(d_out.data_ptr(), obytes, d_ooff.data_ptr(), 0, d_olen.data_ptr(), n, rx, d_res.data_ptr(), stream())
+    torch.cuda.synchronize()
+    got = results_to_numpy(d_res)
+    exp = oracle_over_device_arena(d_out, ooff, olen, rx)
+    bad = np.nonzero(got != exp)[0]
+    assert bad.size == 0, (bad[:5], got[bad[:5]], exp[bad[:5]], plen[bad[:5]])
+    ours = ~refused & ~elsewhere
+    v = exp["verdict"]
+    assert (v[ours & ~icmp] == Verdict.ACCEPT_UDP).all()
+    assert (v[ours & icmp] == Verdict.ACCEPT_ICMP_ECHO).all()
+    assert (v[elsewhere & ~refused] == (Verdict.IGNORE_L3_NOT_FOR_ME)).all()
