@@ -150,7 +150,7 @@ int unet_hint_max_len(unet_ctx* ctx, uint32_t max_len);
  * 1.  A pure function of its arguments that touches no GPU -- for logs, for sizing experiments with UNET_TILE, and
  * so that the rule can be tested without a device.  (No counterpart in the reference, which has no batches.) */
 int unet_records_per_wave(uint32_t mean_len, uint32_t max_len);
-/* The same for unet_tx_build*: packets per wavefront by mean payload length -- 64, 32, 16 or 8 up to 1 KiB; above that 1:
+/* The same for unet_tx_build*: packets per wavefront by mean payload length -- 64, 32, 16 or 8 up to 1152 bytes; above that 1:
  * every packet is built by a wavefront of its own, or by unet_tx_waves_per_packet (1, 2, 4, 8 or 16, about three 1 KiB
  * rows of output each) wavefronts of one workgroup.  (UNET_TX_WAVE=0 in the environment of unet_open keeps such
  * batches on the tile kernel, 8, 4, 2 or 1 packets per wavefront: for A/B measurements.) */

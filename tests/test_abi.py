@@ -63,9 +63,9 @@ def test_records_per_wave_rule():
 
 def test_tx_packets_per_wave_rule():
     tpw = _ffi.tx_packets_per_wave
-    assert [tpw(0), tpw(18), tpw(128), tpw(129), tpw(320), tpw(321), tpw(720), tpw(721), tpw(1024), tpw(1025)] == [64, 64, 64, 32, 32, 16, 16, 8, 8, 1]
+    assert [tpw(0), tpw(18), tpw(128), tpw(129), tpw(320), tpw(321), tpw(720), tpw(721), tpw(1024), tpw(1025), tpw(1152), tpw(1153)] == [64, 64, 64, 32, 32, 16, 16, 8, 8, 8, 8, 1]
     assert [tpw(1472), tpw(2500), tpw(8972), tpw(65507)] == [1, 1, 1, 1]
-    # above 1 KiB of mean payload: one packet per wavefront, or per group of wavefronts -- about three 1 KiB rows of output each
+    # above 1152 bytes of mean payload: one packet per wavefront, or per group of wavefronts -- about three 1 KiB rows of output each
     wpp = _ffi.tx_waves_per_packet
     assert [wpp(0), wpp(1024), wpp(1025), wpp(1472), wpp(3044), wpp(3045), wpp(6116), wpp(6117)] == [1, 1, 1, 1, 1, 2, 2, 4]
     assert [wpp(12260), wpp(12261), wpp(24548), wpp(24549), wpp(65507)] == [4, 8, 8, 16, 16]

@@ -380,8 +380,14 @@ inline int tx_tile_long(u64 mean_payload) {
     return mean_payload < 8000 ? 2 : 1;
 }
 
+// Mean payload above which a batch goes to k_tx_build_wave.  Not at 1 KiB, where a packet begins to need a second row:
+// up to about 1150 bytes the tile kernel's eight packets per wave are still ahead (1040 B 5.55 against 4.94 TB/s on
+// lines, 5.64 against 4.99 as packed Ethernet frames; 1100 B 5.76 / 5.23 and 5.77 / 5.28; packed raw IP even), at 1200
+// bytes the wave kernel is (5.66 against 5.25 packed).
+constexpr u64 kTxWaveFrom = 1152;
+
 // Packets per wave of k_tx_build by mean payload length.  Up to 128 bytes (one lane or four to a packet) 64, up to 320
-// bytes 32, up to 720 bytes sixteen, up to 1 KiB eight; above 1 KiB see tx_tile_long.  The steps follow what a wave's LDS
+// bytes 32, up to 720 bytes sixteen, up to kTxWaveFrom eight (above 1 KiB by way of tx_tile_long).  The steps follow what a wave's LDS
 // staging area holds (496-622 chunks of output: 64 packets of up to seven chunks, 32 of up to seventeen, 16 of up to 37,
 // 8 of up to 77) and what measured best where a tile is staged in part or not at all: 100 B 64 against 32 per wave
 // 5.46 / 4.96 TB/s, 128 B 5.66 / 5.50 (Ethernet: the same either way), 200 B 5.16 / 5.35; 280 B 5.30 with 32 (not staged) against 5.22 with 16 (staged), 400 B
@@ -584,9 +590,9 @@ int unet_hint_max_len(unet_ctx* c, uint32_t max_len) {
 }
 
 int unet_records_per_wave(uint32_t mean_len, uint32_t max_len) { return tile_for(mean_len, max_len != 0, max_len); }
-int unet_tx_packets_per_wave(uint32_t mean_payload_len) { return mean_payload_len > 1024 ? 1 : tx_tile_for(mean_payload_len); }
+int unet_tx_packets_per_wave(uint32_t mean_payload_len) { return mean_payload_len > kTxWaveFrom ? 1 : tx_tile_for(mean_payload_len); }
 int unet_tx_waves_per_packet(uint32_t mean_payload_len, int mode) {
-    return mean_payload_len > 1024 ? 1 << tx_group_log2_for(mean_payload_len, mode == UNET_MODE_L2) : 1;
+    return mean_payload_len > kTxWaveFrom ? 1 << tx_group_log2_for(mean_payload_len, mode == UNET_MODE_L2) : 1;
 }
 
 int unet_device_count(void) {
@@ -1357,7 +1363,7 @@ int unet_tx_build_opts_dev(unet_ctx* ctx, void* stream, const uint8_t* d_payload
     b.tile_n = (u32)tile;  // fewer packets per wave than the smallest instantiation: that kernel, part of its lanes
     // Long payloads (mean above 1 KiB): one packet per wave or group of waves, see k_tx_build_wave.  (A launch holds
     // fewer than 2^32 threads; a batch too large for that stays with the tile kernel.)
-    if (ctx->tx_wave == 2 || (ctx->tx_wave == 1 && !ctx->tx_tile_override && mean_payload > 1024)) {
+    if (ctx->tx_wave == 2 || (ctx->tx_wave == 1 && !ctx->tx_tile_override && mean_payload > kTxWaveFrom)) {
         const u32 g2 = ctx->tx_group_log2 >= 0 ? (u32)ctx->tx_group_log2 : tx_group_log2_for(mean_payload, iface->mode == UNET_MODE_L2);
         const u32 group = 1u << g2;
         const u32 wpb = group > ctx->tx_wave_block / kWave ? group : ctx->tx_wave_block / kWave;  // waves per workgroup
